@@ -1,0 +1,352 @@
+"""fem_amd -- ctypes plumbing over libfem_hip.so (the C-ABI in include/fem_hip.h).
+
+The product is the shared library (host C++ + hand-written gfx950 kernels);
+this module only binds it for tests, bench.py and Python callers.  There is
+no CPU fallback: importing fails loudly when the library has not been built
+(`make -C fem_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfem_hip.so")
+
+PREC_MIXED, PREC_F64, PREC_F32 = 0, 1, 2
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "fem_amd: %s is missing -- build it first (make -C fem_amd/csrc). "
+        "There is no fallback path." % LIB_PATH)
+lib = C.CDLL(LIB_PATH)
+
+u32p = C.POINTER(C.c_uint32)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+f64p = C.POINTER(C.c_double)
+u8p = C.POINTER(C.c_uint8)
+vp = C.c_void_p
+
+
+class Model(C.Structure):
+    """fem_model: constants of reference src/FEM_common.cu:9-13 as data."""
+    _fields_ = [("nMax", C.c_double), ("D", C.c_double), ("r", C.c_double),
+                ("alpha", C.c_double), ("S", C.c_double)]
+
+    def as_array(self):
+        return np.array([self.nMax, self.D, self.r, self.alpha, self.S])
+
+
+class FemError(RuntimeError):
+    pass
+
+
+lib.fem_error_string.restype = C.c_char_p
+lib.fem_error_detail.restype = C.c_char_p
+lib.fem_plan_operator_bytes.restype = C.c_uint64
+lib.fem_plan_operator_bytes.argtypes = [vp]
+lib.fem_free.argtypes = [vp]
+for _name in ("fem_mesh_destroy", "fem_ref_layout_destroy", "fem_ref_device_destroy", "fem_plan_destroy"):
+    getattr(lib, _name).argtypes = [vp]
+    getattr(lib, _name).restype = None
+
+
+def _check(rc):
+    if rc < 0:
+        raise FemError("%s (%d): %s" % (lib.fem_error_string(rc).decode(), rc,
+                                        lib.fem_error_detail().decode()))
+    return rc
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def default_model():
+    m = Model()
+    lib.fem_default_model(C.byref(m))
+    return m
+
+
+def _take(ptr, n, dtype):
+    """copy a malloc'ed C array into numpy and free it"""
+    out = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    lib.fem_free(C.cast(ptr, vp))
+    return out
+
+
+def _mesh_out(fn, *args):
+    V, F = C.c_int(), C.c_int()
+    pts, tri = f64p(), u32p()
+    _check(fn(*args, C.byref(V), C.byref(F), C.byref(pts), C.byref(tri)))
+    return (_take(pts, 3 * V.value, np.float64).reshape(-1, 3),
+            _take(tri, 3 * F.value, np.uint32).reshape(-1, 3))
+
+
+def make_icosphere(nu, edge=0.1):
+    return _mesh_out(lib.fem_make_icosphere, C.c_int(nu), C.c_double(edge))
+
+
+def make_strip(nx=11, ny=41, h=0.1):
+    return _mesh_out(lib.fem_make_strip, C.c_int(nx), C.c_int(ny), C.c_double(h))
+
+
+def off_read(path):
+    V, F = C.c_int(), C.c_int()
+    pts, tri, rgb = f64p(), u32p(), u8p()
+    _check(lib.fem_off_read(path.encode(), C.byref(V), C.byref(F), C.byref(pts), C.byref(tri), C.byref(rgb)))
+    colors = _take(rgb, 3 * V.value, np.uint8).reshape(-1, 3) if rgb else None
+    return (_take(pts, 3 * V.value, np.float64).reshape(-1, 3),
+            _take(tri, 3 * F.value, np.uint32).reshape(-1, 3), colors)
+
+
+def off_write(path, points, tri, rgb=None):
+    points = np.ascontiguousarray(points, np.float64)
+    tri = np.ascontiguousarray(tri, np.uint32)
+    rgbp = None
+    if rgb is not None:
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        rgbp = _ptr(rgb, u8p)
+    _check(lib.fem_off_write(path.encode(), len(points), len(tri), _ptr(points, f64p), _ptr(tri, u32p), rgbp))
+
+
+def initial_condition(V, seed=1, nMax=1.0):
+    n, c = np.empty(V), np.empty(V)
+    lib.fem_initial_condition(C.c_int(V), C.c_uint32(seed), C.c_double(nMax), _ptr(n, f64p), _ptr(c, f64p))
+    return n, c
+
+
+class Mesh:
+    """fem_mesh handle: points + faces + half-edge tables (+ stats once initialised)."""
+
+    def __init__(self, points=None, tri=None, handle=None):
+        if handle is None:
+            points = np.ascontiguousarray(points, np.float64)
+            tri = np.ascontiguousarray(tri, np.uint32)
+            h = vp()
+            _check(lib.fem_mesh_create(len(points), len(tri), _ptr(points, f64p), _ptr(tri, u32p), C.byref(h)))
+            handle = h
+        self.h = handle
+        V, F, H = C.c_int(), C.c_int(), C.c_int()
+        lib.fem_mesh_counts(self.h, C.byref(V), C.byref(F), C.byref(H))
+        self.V, self.F, self.H = V.value, F.value, H.value
+        self.precision = None
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.fem_mesh_destroy(self.h)
+            self.h = None
+
+    def _view(self, ptr, n, shape=None):
+        a = np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n else np.zeros(0)
+        return a.reshape(shape) if shape else a
+
+    @property
+    def points(self):
+        p, t = f64p(), u32p()
+        lib.fem_mesh_arrays(self.h, C.byref(p), C.byref(t))
+        return self._view(p, 3 * self.V, (-1, 3))
+
+    @property
+    def tri(self):
+        p, t = f64p(), u32p()
+        lib.fem_mesh_arrays(self.h, C.byref(p), C.byref(t))
+        return self._view(t, 3 * self.F, (-1, 3))
+
+    def topology(self):
+        opp, hf, ht, rp, col, rh = i32p(), u32p(), u32p(), i32p(), u32p(), i32p()
+        lib.fem_mesh_topology(self.h, C.byref(opp), C.byref(hf), C.byref(ht), C.byref(rp), C.byref(col), C.byref(rh))
+        H, V = self.H, self.V
+        return dict(opp=self._view(opp, H), he_from=self._view(hf, H), he_to=self._view(ht, H),
+                    rowptr=self._view(rp, V + 1), col=self._view(col, H), row_he=self._view(rh, H))
+
+    def init_stats(self, precision=PREC_MIXED):
+        _check(lib.fem_mesh_init_stats(self.h, C.c_int(precision)))
+        self.precision = precision
+        return self
+
+    def stats(self):
+        ps = [f64p() for _ in range(8)]
+        mx = C.c_double()
+        _check(lib.fem_mesh_stats(self.h, C.byref(ps[0]), C.byref(ps[1]), C.byref(ps[2]), C.byref(ps[3]),
+                                  C.byref(ps[4]), C.byref(ps[5]), C.byref(mx), C.byref(ps[6]), C.byref(ps[7])))
+        H, V, F = self.H, self.V, self.F
+        return dict(meshAngle=self._view(ps[0], H), meshCot=self._view(ps[1], H), meshArea=self._view(ps[2], F),
+                    areaPerVtx=self._view(ps[3], V), wHej=self._view(ps[4], H), wVtx=self._view(ps[5], V),
+                    maxEdgeLen=mx.value, gradVec12=self._view(ps[6], 3 * F, (-1, 3)),
+                    gradVec13=self._view(ps[7], 3 * F, (-1, 3)))
+
+    def laplacian_cpu(self, fn):
+        fn = np.ascontiguousarray(fn, np.float64)
+        out = np.empty(self.V)
+        _check(lib.fem_compute_laplacian_cpu(self.h, _ptr(fn, f64p), _ptr(out, f64p)))
+        return out
+
+    def face_gradients_cpu(self, fn):
+        fn = np.ascontiguousarray(fn, np.float64)
+        out = np.empty((self.F, 3))
+        _check(lib.fem_compute_face_gradients_cpu(self.h, _ptr(fn, f64p), _ptr(out, f64p)))
+        return out
+
+    def vertex_gradients_cpu(self, face_grad):
+        fg = np.ascontiguousarray(face_grad, np.float64)
+        out = np.empty((self.V, 3))
+        _check(lib.fem_compute_vertex_gradients_cpu(self.h, _ptr(fg, f64p), _ptr(out, f64p)))
+        return out
+
+    def partition_vertices(self, n):
+        npart = np.empty(self.V, np.int64)
+        _check(lib.fem_partition_vertices(self.h, C.c_int(n), _ptr(npart, i64p)))
+        return npart
+
+    def partition(self, n, npart=None):
+        """-> Partition (perm_v, perm_f, node_parts, element_parts, ordered Mesh, cut)"""
+        perm_v, perm_f = np.empty(self.V, np.int64), np.empty(self.F, np.int64)
+        node_parts, element_parts = np.empty(n + 1, np.uint32), np.empty(n + 2, np.uint32)
+        oh = vp()
+        if npart is None:
+            cut = _check(lib.fem_partition(self.h, C.c_int(n), _ptr(perm_v, i64p), _ptr(perm_f, i64p),
+                                           _ptr(node_parts, u32p), _ptr(element_parts, u32p), C.byref(oh)))
+        else:
+            npart = np.ascontiguousarray(npart, np.int64)
+            cut = _check(lib.fem_partition_apply(self.h, C.c_int(n), _ptr(npart, i64p), _ptr(perm_v, i64p),
+                                                 _ptr(perm_f, i64p), _ptr(node_parts, u32p),
+                                                 _ptr(element_parts, u32p), C.byref(oh)))
+        return Partition(n, perm_v, perm_f, node_parts, element_parts, Mesh(handle=oh), cut)
+
+
+class Partition:
+    def __init__(self, n, perm_v, perm_f, node_parts, element_parts, ordered, cut):
+        self.n, self.perm_v, self.perm_f = n, perm_v, perm_f
+        self.node_parts, self.element_parts, self.ordered, self.cut = node_parts, element_parts, ordered, cut
+
+
+class RefLayout:
+    """Reference device layout (initializeGPUData, reference src/main.cpp:207-342)."""
+
+    def __init__(self, part):
+        self.part = part
+        h = vp()
+        _check(lib.fem_ref_layout_create(part.ordered.h, C.c_int(part.n), _ptr(part.node_parts, u32p),
+                                         _ptr(part.element_parts, u32p), C.byref(h)))
+        self.h = h
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.fem_ref_layout_sizes(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.maxV, self.W, self.maxF, self.n_halo = a.value, b.value, c.value, d.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.fem_ref_layout_destroy(self.h)
+            self.h = None
+
+    def arrays(self):
+        n, maxV, W, maxF = self.part.n, self.maxV, self.W, self.maxF
+        hk, hf, bfc, nbr, fv = u32p(), u32p(), u32p(), u32p(), u32p()
+        vw, vvw, fvw = f64p(), f64p(), f64p()
+        heg = C.POINTER(C.c_float)()
+        lib.fem_ref_layout_arrays(self.h, C.byref(hk), C.byref(hf), C.byref(bfc), C.byref(vw), C.byref(nbr),
+                                  C.byref(vvw), C.byref(fv), C.byref(fvw), C.byref(heg))
+
+        def view(p, shape):
+            cnt = int(np.prod(shape))
+            return np.ctypeslib.as_array(p, shape=(cnt,)).copy().reshape(shape) if cnt else np.zeros(shape)
+        return dict(halo_faces_keys=view(hk, (n + 1,)), halo_faces=view(hf, (self.n_halo,)),
+                    block_face_count=view(bfc, (n,)), vertex_weights=view(vw, (n, maxV)),
+                    nbr_v=view(nbr, (n, W + 1, maxV)), vv_weights=view(vvw, (n, W, maxV)),
+                    face_vertices=view(fv, (n, 3, maxF)), fv_weights_new=view(fvw, (n, 3, maxF)),
+                    he_grads=view(heg, (n, 2, maxF, 4)))
+
+
+class RefDevice:
+    """Pitched device copies of a RefLayout + two double2 state buffers (GPUrun, main.cpp:344-452)."""
+
+    def __init__(self, layout):
+        self.layout = layout
+        part = layout.part
+        h = vp()
+        _check(lib.fem_ref_device_create(layout.h, _ptr(part.node_parts, u32p), C.c_int(part.ordered.V), C.byref(h)))
+        self.h, self.V = h, part.ordered.V
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.fem_ref_device_destroy(self.h)
+            self.h = None
+
+    def set_state(self, n, c):
+        fn = np.ascontiguousarray(np.stack([n, c], axis=1), np.float64)
+        _check(lib.fem_ref_device_set_state(self.h, _ptr(fn, f64p)))
+
+    def get_state(self):
+        fn = np.empty((self.V, 2))
+        _check(lib.fem_ref_device_get_state(self.h, _ptr(fn, f64p)))
+        return fn[:, 0].copy(), fn[:, 1].copy()
+
+    def run(self, nsteps, dt, model=None, stream=None):
+        mp = C.byref(model) if model is not None else None
+        _check(lib.fem_ref_device_run(self.h, C.c_int(nsteps), C.c_double(dt), mp, vp(stream or 0)))
+
+    def args(self):
+        """raw device pointers / pitches in step()'s argument order (for direct step() calls)"""
+        u64 = [C.c_uint64() for _ in range(10)]
+        u32 = [C.c_uint32() for _ in range(10)]
+        (fn_one, fn_two, fv, fvw, nbr, vtxW, vvw, grads, parts_n, bfc) = u64
+        (fv_p, fvw_p, vw_p, vv_p, vws_p, vv_size, he_p, blocks, threads, smem) = u32
+        lib.fem_ref_device_args(self.h, C.byref(fn_one), C.byref(fn_two), C.byref(fv), C.byref(fvw), C.byref(fv_p),
+                                C.byref(fvw_p), C.byref(nbr), C.byref(vtxW), C.byref(vw_p), C.byref(vvw),
+                                C.byref(vv_p), C.byref(vws_p), C.byref(vv_size), C.byref(grads), C.byref(he_p),
+                                C.byref(parts_n), C.byref(bfc), C.byref(blocks), C.byref(threads), C.byref(smem))
+        return dict(fn_one=fn_one.value, fn_two=fn_two.value, fv=fv.value, fv_weights=fvw.value,
+                    fv_pitch=fv_p.value, fvw_pitch=fvw_p.value, nbr=nbr.value, vtxW=vtxW.value,
+                    vw_pitch=vw_p.value, vertex_weights=vvw.value, vv_pitch=vv_p.value, vws_pitch=vws_p.value,
+                    vv_size=vv_size.value, grads=grads.value, he_pitch=he_p.value, parts_n=parts_n.value,
+                    block_face_count=bfc.value, blocks=blocks.value, threads=threads.value, smem_size=smem.value)
+
+
+# the reference's own symbol, bound with its 21-argument signature (FEM_common.h:3-25)
+lib.step.restype = None
+lib.step.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32,
+                     C.c_uint32, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, C.c_double, C.c_uint32]
+
+
+def step(a, src, dst, dt):
+    """call the reference-signature `step` with the device arrays of RefDevice.args()"""
+    lib.step(a[src], a[dst], a["fv"], a["fv_weights"], a["fv_pitch"], a["fvw_pitch"], a["nbr"], a["vtxW"],
+             a["vw_pitch"], a["vertex_weights"], a["vv_pitch"], a["vws_pitch"], a["vv_size"], a["grads"],
+             a["he_pitch"], a["parts_n"], a["block_face_count"], a["blocks"], a["threads"], dt, a["smem_size"])
+    _check(lib.fem_last_error())
+
+
+class Plan:
+    """Native plan: sliced-ELL operator + ping-pong state on the device."""
+
+    def __init__(self, ordered, precision=PREC_F32):
+        h = vp()
+        _check(lib.fem_plan_create(ordered.h, C.c_int(precision), C.byref(h)))
+        self.h, self.V, self.precision = h, ordered.V, precision
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.fem_plan_destroy(self.h)
+            self.h = None
+
+    def set_state(self, n, c):
+        n, c = np.ascontiguousarray(n, np.float64), np.ascontiguousarray(c, np.float64)
+        _check(lib.fem_plan_set_state(self.h, _ptr(n, f64p), _ptr(c, f64p)))
+
+    def get_state(self):
+        n, c = np.empty(self.V), np.empty(self.V)
+        _check(lib.fem_plan_get_state(self.h, _ptr(n, f64p), _ptr(c, f64p)))
+        return n, c
+
+    def run(self, nsteps, dt, model=None, stream=None):
+        mp = C.byref(model) if model is not None else None
+        _check(lib.fem_plan_run(self.h, C.c_int(nsteps), C.c_double(dt), mp, vp(stream or 0)))
+
+    def operator_bytes(self):
+        return lib.fem_plan_operator_bytes(self.h)
+
+    def state_ptr(self):
+        p, nv, sb = C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(lib.fem_plan_state(self.h, C.byref(p), C.byref(nv), C.byref(sb)))
+        return p.value, nv.value, sb.value

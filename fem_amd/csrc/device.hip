@@ -1,0 +1,481 @@
+// device.hip -- gfx950 kernels and the device half of the C-ABI.
+//
+//   ref_step_kernel  : the reference's fused time step on the reference's own
+//                      padded SoA layout (what `step` launches; reference
+//                      src/FEM_common.cu:82-180), one workgroup per partition.
+//   sell_step_kernel : the native time step on the sliced-ELL layout with
+//                      folded gradient coefficients (pack.cpp), one wave64 per
+//                      64-row slice, no atomics, no LDS.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fem_host.hpp"
+
+namespace fem {
+thread_local int g_last_error = FEM_OK;
+thread_local std::string g_error_detail;
+int fail(int status, const char *what) {
+  g_last_error = status;
+  g_error_detail = what ? what : "";
+  return status;
+}
+}  // namespace fem
+
+namespace {
+
+int fail(int status, const char *what, hipError_t e = hipSuccess) {
+  fem::fail(status, what);
+  if (e != hipSuccess) { fem::g_error_detail += ": "; fem::g_error_detail += hipGetErrorString(e); }
+  return status;
+}
+
+#define HIP_TRY(call)                                          \
+  do {                                                         \
+    hipError_t e_ = (call);                                    \
+    if (e_ != hipSuccess) return fail(FEM_ERR_DEVICE, #call, e_); \
+  } while (0)
+
+struct ModelD { double nMax, D, r, alpha, S; };
+
+// ---------------------------------------------------------------------------
+// Reference-layout step (FEM_common.cu:82-166).  Differences from the reference
+// kernel, none of them in the arithmetic: all loops are block-strided, so no
+// thread leaves before a barrier and a partition may hold more faces or
+// vertices than the block has threads (the reference returns early at :99-100
+// and :138-139); the double accumulator uses the LDS f64 add instead of a CAS
+// loop (:15-31).
+// LDS: wg[size] double, then nvGrads[3*size], cvGrads[3*size] float = 32 B/vertex.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ref_step_kernel(
+    const double2 *__restrict__ fn_src, double2 *__restrict__ fn_dst, const uint *__restrict__ fv,
+    const double *__restrict__ fv_weights, uint fv_pitch, uint fvw_pitch, const uint *__restrict__ nbr,
+    const double *__restrict__ vtxW, uint vw_pitch, const double *__restrict__ vertex_weights,
+    uint vv_pitch, uint vws_pitch, uint vv_size, const float4 *__restrict__ grads, uint he_pitch,
+    const uint *__restrict__ vertex_parts, const uint *__restrict__ block_face_count, double dt,
+    ModelD m) {
+  extern __shared__ double s_mem[];
+  const uint p = blockIdx.x;
+  const uint base = vertex_parts[p];
+  const uint size = vertex_parts[p + 1] - base;
+  double *s_wg = s_mem;
+  float *s_nv = reinterpret_cast<float *>(s_wg + size);
+  float *s_cv = s_nv + 3 * size;
+
+  for (uint i = threadIdx.x; i < size; i += blockDim.x) {
+    s_wg[i] = 0.0;
+    s_nv[3 * i] = s_nv[3 * i + 1] = s_nv[3 * i + 2] = 0.0f;
+    s_cv[3 * i] = s_cv[3 * i + 1] = s_cv[3 * i + 2] = 0.0f;
+  }
+  __syncthreads();
+
+  /* face gradients, scattered to the owned corners */
+  const uint nfaces = block_face_count[p];
+  const size_t fvb = (size_t)p * 3 * fv_pitch, fwb = (size_t)p * 3 * fvw_pitch, heb = (size_t)p * 2 * he_pitch;
+  for (uint t = threadIdx.x; t < nfaces; t += blockDim.x) {
+    const uint i0 = fv[fvb + t], i1 = fv[fvb + fv_pitch + t], i2 = fv[fvb + 2 * (size_t)fv_pitch + t];
+    const double2 v1 = fn_src[i2], a = fn_src[i0], b = fn_src[i1];
+    const float d12x = (float)(a.x - v1.x), d12y = (float)(a.y - v1.y);
+    const float d13x = (float)(b.x - v1.x), d13y = (float)(b.y - v1.y);
+    const float4 g12 = grads[heb + t], g13 = grads[heb + he_pitch + t];
+    const float nvx = g12.x * d12x + g13.x * d13x, nvy = g12.y * d12x + g13.y * d13x, nvz = g12.z * d12x + g13.z * d13x;
+    const float cvx = g12.x * d12y + g13.x * d13y, cvy = g12.y * d12y + g13.y * d13y, cvz = g12.z * d12y + g13.z * d13y;
+    const uint idx[3] = {i0, i1, i2};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint li = idx[j] - base;              // unsigned wrap makes "below base" large
+      if (li < size) {
+        const double weight = fv_weights[fwb + (size_t)j * fvw_pitch + t];
+        atomicAdd(&s_nv[3 * li], (float)(nvx * weight));
+        atomicAdd(&s_nv[3 * li + 1], (float)(nvy * weight));
+        atomicAdd(&s_nv[3 * li + 2], (float)(nvz * weight));
+        atomicAdd(&s_cv[3 * li], (float)(cvx * weight));
+        atomicAdd(&s_cv[3 * li + 1], (float)(cvy * weight));
+        atomicAdd(&s_cv[3 * li + 2], (float)(cvz * weight));
+        unsafeAtomicAdd(&s_wg[li], weight);
+      }
+    }
+  }
+  __syncthreads();
+
+  /* laplacian, vertex gradients, update */
+  const size_t nb = (size_t)p * (vv_size + 1) * vv_pitch, wb = (size_t)p * vv_size * vws_pitch;
+  for (uint t = threadIdx.x; t < size; t += blockDim.x) {
+    const uint i = base + t;
+    const double2 s = fn_src[i];
+    const double vW = vtxW[(size_t)p * vw_pitch + t];
+    double lx = s.x * vW, ly = s.y * vW;
+    const uint end = nbr[nb + t];
+    for (uint j = 0; j < end; j++) {
+      const uint nIdx = nbr[nb + (size_t)vv_pitch * (j + 1) + t];
+      const double hW = vertex_weights[wb + (size_t)vws_pitch * j + t];
+      const double2 f = fn_src[nIdx];
+      lx += f.x * hW; ly += f.y * hW;
+    }
+    double dotP = 0;
+    const double wg = s_wg[t];
+    if (wg > 0) {
+      const float w = (float)wg;
+      dotP = (s_nv[3 * t] / w) * (s_cv[3 * t] / w) + (s_nv[3 * t + 1] / w) * (s_cv[3 * t + 1] / w) +
+             (s_nv[3 * t + 2] / w) * (s_cv[3 * t + 2] / w);
+    }
+    const double dauN = m.D * lx - m.alpha * s.x * ly - m.alpha * dotP + m.S * m.r * s.x * (m.nMax - s.x);
+    const double dauC = ly + m.S * (s.x / (1 + s.x) - s.y);
+    double2 o;
+    o.x = dt * dauN + s.x > 0 ? dt * dauN + s.x : 0.0;
+    o.y = dt * dauC + s.y > 0 ? dt * dauC + s.y : 0.0;
+    fn_dst[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Native step.  One wave64 per slice; entry (k, lane) of a slice lives at
+// slice_off + k*64 + lane, so every operator load is one fully coalesced
+// 256-B (idx) or 1-KiB (coef, fp32) wave access; neighbour state is gathered
+// from global memory (L1/L2-resident: a slice's neighbours are a few KB).
+// Workgroups are renumbered so that consecutive slices run on one XCD and share
+// its L2 (workgroups are dealt round-robin over the 8 XCDs).
+// Algorithmic bytes per vertex (fp32, valence 6): 6*(4+16) operator + 8 state
+// read + 8 state write = 136 B (+ gathers served on chip).
+// ---------------------------------------------------------------------------
+template <typename T> struct Vec;
+template <> struct Vec<float> { typedef float2 t2; typedef float4 t4; };
+template <> struct Vec<double> { typedef double2 t2; typedef double4 t4; };
+
+template <typename T> struct ModelT { T nMax, D, r, alpha, S, dt; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void sell_step_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
+    const uint *__restrict__ slice_off, const uint *__restrict__ idx,
+    const typename Vec<T>::t4 *__restrict__ coef, uint V, uint nslices, uint nblocks, ModelT<T> m) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  // bijective XCD remap: blocks b, b+8, b+16, ... (one XCD) get consecutive slices
+  const uint b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7u, x = b & 7u;
+  const uint lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  const uint slice = lb * 4 + (threadIdx.x >> 6);
+  if (slice >= nslices) return;
+  const uint lane = threadIdx.x & 63u;
+  const uint off = __builtin_amdgcn_readfirstlane(slice_off[slice]);
+  const uint end = __builtin_amdgcn_readfirstlane(slice_off[slice + 1]);
+  const uint v = slice * 64 + lane;
+  const uint vs = v < V ? v : V - 1;
+  const T2 s = src[vs];
+  T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+#pragma unroll 2
+  for (uint e = off + lane; e < end; e += 64) {
+    const uint j = idx[e];
+    const T4 c = coef[e];
+    const T2 f = src[j];
+    const T dn = f.x - s.x, dc = f.y - s.y;
+    lapn += c.x * dn; lapc += c.x * dc;
+    gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+    gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+  }
+  const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
+  const T dauN = m.D * lapn - m.alpha * s.x * lapc - m.alpha * dotP + m.S * m.r * s.x * (m.nMax - s.x);
+  const T dauC = lapc + m.S * (s.x / (1 + s.x) - s.y);
+  T2 o;
+  o.x = m.dt * dauN + s.x > 0 ? m.dt * dauN + s.x : (T)0;
+  o.y = m.dt * dauC + s.y > 0 ? m.dt * dauC + s.y : (T)0;
+  if (v < V) dst[v] = o;
+}
+
+template <typename T> struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    n = count;
+    return hipMalloc((void **)&p, sizeof(T) * (count ? count : 1));
+  }
+  hipError_t upload(const T *h) { return hipMemcpy(p, h, sizeof(T) * n, hipMemcpyHostToDevice); }
+  void release() { if (p) (void)hipFree(p); p = nullptr; }
+};
+
+size_t pitchFor(size_t widthBytes) { return (widthBytes + 511) / 512 * 512; }   // cudaMallocPitch-like
+
+}  // namespace
+
+// ===========================================================================
+// C-ABI, device half
+// ===========================================================================
+
+struct fem_ref_device {
+  int n = 0, V = 0;
+  fem_uint maxV = 0, W = 0, maxF = 0, threads = 0, smem = 0;
+  size_t vw_pitch = 0, nbr_pitch = 0, vvw_pitch = 0, he_pitch = 0, fv_pitch = 0, fvw_pitch = 0;
+  double2 *fn_one = nullptr, *fn_two = nullptr;
+  double *vtxW = nullptr, *vv_weights = nullptr, *fv_weights = nullptr;
+  fem_uint *nbr = nullptr, *fv = nullptr, *parts_n = nullptr, *bfc = nullptr;
+  float4 *he_grads = nullptr;
+  bool one_is_current = true;
+};
+
+struct fem_plan {
+  int precision = FEM_PREC_F32;
+  fem_uint V = 0, nslices = 0, nblocks = 0;
+  size_t entries = 0;
+  DevBuf<fem_uint> slice_off, idx;
+  void *coef = nullptr;            // float4 / double4 [entries]
+  void *state[2] = {nullptr, nullptr};
+  int cur = 0;
+};
+
+extern "C" {
+
+int fem_last_error(void) { return fem::g_last_error; }
+const char *fem_error_detail(void) { return fem::g_error_detail.c_str(); }
+
+int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
+             fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
+             fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
+             fem_uint vws_pitchInBytes, fem_uint vv_size, fem_float4 *grads,
+             fem_uint he_pitchInBytes, fem_uint *parts_n, fem_uint *block_face_count,
+             fem_uint blocks, double dt, fem_uint max_part_vertices, const fem_model *model,
+             void *stream) {
+  if (blocks == 0) return FEM_OK;
+  if (!fn_src || !fn_dst || !fv || !fv_weights || !nbr || !vtxW || !vertex_weights || !grads ||
+      !parts_n || !block_face_count || fn_src == fn_dst)
+    return fail(FEM_ERR_INVALID, "fem_step: null or aliased pointer");
+  if (fv_pitchInBytes % sizeof(fem_uint) || fvw_pitchInBytes % sizeof(double) ||
+      vw_pitchInBytes % sizeof(double) || vv_pitchInBytes % sizeof(fem_uint) ||
+      vws_pitchInBytes % sizeof(double) || he_pitchInBytes % sizeof(fem_float4))
+    return fail(FEM_ERR_INVALID, "fem_step: pitch not a multiple of the element size");
+  const size_t lds = (size_t)max_part_vertices * 32;         // main.cpp:369
+  if (max_part_vertices == 0 || lds > 160 * 1024)
+    return fail(FEM_ERR_LIMIT, "fem_step: partition too large for the LDS accumulators (<= 5120 vertices)");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  ModelD m = {model->nMax, model->D, model->r, model->alpha, model->S};
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute((const void *)ref_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(ref_step_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream,
+                     (const double2 *)fn_src, (double2 *)fn_dst, fv, fv_weights,
+                     fv_pitchInBytes / (fem_uint)sizeof(fem_uint), fvw_pitchInBytes / (fem_uint)sizeof(double),
+                     nbr, vtxW, vw_pitchInBytes / (fem_uint)sizeof(double), vertex_weights,
+                     vv_pitchInBytes / (fem_uint)sizeof(fem_uint), vws_pitchInBytes / (fem_uint)sizeof(double),
+                     vv_size, (const float4 *)grads, he_pitchInBytes / (fem_uint)sizeof(fem_float4), parts_n,
+                     block_face_count, dt, m);
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
+          fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
+          fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
+          fem_uint vws_pitchInBytes, fem_uint vv_size, fem_float4 *grads, fem_uint he_pitchInBytes,
+          fem_uint *parts_n, fem_uint *block_face_count, fem_uint blocks, fem_uint threads,
+          double dt, fem_uint smem_size) {
+  (void)threads;
+  // the reference caller sizes smem as 32 B per vertex of the largest partition (main.cpp:369)
+  (void)fem_step(fn_src, fn_dst, fv, fv_weights, fv_pitchInBytes, fvw_pitchInBytes, nbr, vtxW,
+                 vw_pitchInBytes, vertex_weights, vv_pitchInBytes, vws_pitchInBytes, vv_size, grads,
+                 he_pitchInBytes, parts_n, block_face_count, blocks, dt, (smem_size + 31) / 32, nullptr,
+                 nullptr);
+}
+
+// ---- reference device harness (GPUrun, main.cpp:344-452) -------------------
+
+void fem_ref_device_destroy(fem_ref_device *d) {
+  if (!d) return;
+  void *ptrs[] = {d->fn_one, d->fn_two, d->vtxW, d->vv_weights, d->fv_weights, d->nbr, d->fv, d->parts_n, d->bfc, d->he_grads};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete d;
+}
+
+static hipError_t upload2D(void **dev, size_t *pitch, const void *host, size_t widthBytes, size_t rows) {
+  *pitch = pitchFor(widthBytes);
+  hipError_t e = hipMalloc(dev, *pitch * (rows ? rows : 1));
+  if (e != hipSuccess) return e;
+  e = hipMemset(*dev, 0, *pitch * (rows ? rows : 1));
+  if (e != hipSuccess || rows == 0 || widthBytes == 0) return e;
+  return hipMemcpy2D(*dev, *pitch, host, widthBytes, widthBytes, rows, hipMemcpyHostToDevice);
+}
+
+int fem_ref_device_create(const fem_ref_layout *lay, const fem_uint *node_parts, int V, fem_ref_device **out) {
+  if (!lay || !node_parts || !out || V <= 0) return fail(FEM_ERR_INVALID, "fem_ref_device_create: bad argument");
+  const fem::RefLayout &l = lay->l;
+  // limits of GPUrun, main.cpp:357-364 (<= 1024 vertices and faces per partition)
+  if (l.max_vertex_count > 1024 || l.max_face_count > 1024)
+    return fail(FEM_ERR_LIMIT, "ERROR: Too many nodes or elements per Block! (> 1024)");
+  fem_ref_device *d = new fem_ref_device();
+  d->n = l.n; d->V = V; d->maxV = l.max_vertex_count; d->W = l.vv_max_neighbors; d->maxF = l.max_face_count;
+  d->threads = std::max((d->maxV + 31) / 32 * 32, (d->maxF + 31) / 32 * 32);   // main.cpp:366-368
+  d->smem = d->maxV * 32;                                                        // main.cpp:369
+  const size_t n = (size_t)l.n;
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+  ok(hipMalloc((void **)&d->fn_one, sizeof(double2) * (size_t)V)) &&
+  ok(hipMalloc((void **)&d->fn_two, sizeof(double2) * (size_t)V)) &&
+  ok(hipMalloc((void **)&d->parts_n, sizeof(fem_uint) * (n + 1))) &&
+  ok(hipMalloc((void **)&d->bfc, sizeof(fem_uint) * n)) &&
+  ok(hipMemcpy(d->parts_n, node_parts, sizeof(fem_uint) * (n + 1), hipMemcpyHostToDevice)) &&
+  ok(hipMemcpy(d->bfc, l.block_face_count.data(), sizeof(fem_uint) * n, hipMemcpyHostToDevice)) &&
+  ok(upload2D((void **)&d->vtxW, &d->vw_pitch, l.vertex_weights.data(), d->maxV * sizeof(double), n)) &&
+  ok(upload2D((void **)&d->nbr, &d->nbr_pitch, l.nbr_v.data(), d->maxV * sizeof(fem_uint), n * (d->W + 1))) &&
+  ok(upload2D((void **)&d->vv_weights, &d->vvw_pitch, l.vv_weights.data(), d->maxV * sizeof(double), n * d->W)) &&
+  ok(upload2D((void **)&d->he_grads, &d->he_pitch, l.he_grads.data(), d->maxF * sizeof(float4), n * 2)) &&
+  ok(upload2D((void **)&d->fv, &d->fv_pitch, l.face_vertices.data(), d->maxF * sizeof(fem_uint), n * 3)) &&
+  ok(upload2D((void **)&d->fv_weights, &d->fvw_pitch, l.fv_weights_new.data(), d->maxF * sizeof(double), n * 3));
+  if (e != hipSuccess) { fem_ref_device_destroy(d); return fail(FEM_ERR_DEVICE, "fem_ref_device_create", e); }
+  *out = d;
+  return FEM_OK;
+}
+
+int fem_ref_device_set_state(fem_ref_device *d, const fem_double2 *fn) {
+  if (!d || !fn) return fail(FEM_ERR_INVALID, "fem_ref_device_set_state: null");
+  HIP_TRY(hipMemcpy(d->fn_one, fn, sizeof(double2) * (size_t)d->V, hipMemcpyHostToDevice));
+  d->one_is_current = true;
+  return FEM_OK;
+}
+
+int fem_ref_device_get_state(fem_ref_device *d, fem_double2 *fn) {
+  if (!d || !fn) return fail(FEM_ERR_INVALID, "fem_ref_device_get_state: null");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(fn, d->one_is_current ? d->fn_one : d->fn_two, sizeof(double2) * (size_t)d->V, hipMemcpyDeviceToHost));
+  return FEM_OK;
+}
+
+int fem_ref_device_run(fem_ref_device *d, int nsteps, double dt, const fem_model *model, void *stream) {
+  if (!d || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_ref_device_run: bad argument");
+  for (int i = 0; i < nsteps; i++) {
+    double2 *src = d->one_is_current ? d->fn_one : d->fn_two, *dst = d->one_is_current ? d->fn_two : d->fn_one;
+    int rc = fem_step((fem_double2 *)src, (fem_double2 *)dst, d->fv, d->fv_weights, (fem_uint)d->fv_pitch,
+                      (fem_uint)d->fvw_pitch, d->nbr, d->vtxW, (fem_uint)d->vw_pitch, d->vv_weights,
+                      (fem_uint)d->nbr_pitch, (fem_uint)d->vvw_pitch, d->W, (fem_float4 *)d->he_grads,
+                      (fem_uint)d->he_pitch, d->parts_n, d->bfc, (fem_uint)d->n, dt, d->maxV, model, stream);
+    if (rc != FEM_OK) return rc;
+    d->one_is_current = !d->one_is_current;
+  }
+  return FEM_OK;
+}
+
+void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn_two, uint64_t *fv,
+                         uint64_t *fv_weights, fem_uint *fv_pitch, fem_uint *fvw_pitch, uint64_t *nbr,
+                         uint64_t *vtxW, fem_uint *vw_pitch, uint64_t *vertex_weights, fem_uint *vv_pitch,
+                         fem_uint *vws_pitch, fem_uint *vv_size, uint64_t *grads, fem_uint *he_pitch,
+                         uint64_t *parts_n, uint64_t *block_face_count, fem_uint *blocks,
+                         fem_uint *threads, fem_uint *smem_size) {
+  *fn_one = (uint64_t)d->fn_one; *fn_two = (uint64_t)d->fn_two;
+  *fv = (uint64_t)d->fv; *fv_weights = (uint64_t)d->fv_weights;
+  *fv_pitch = (fem_uint)d->fv_pitch; *fvw_pitch = (fem_uint)d->fvw_pitch;
+  *nbr = (uint64_t)d->nbr; *vtxW = (uint64_t)d->vtxW; *vw_pitch = (fem_uint)d->vw_pitch;
+  *vertex_weights = (uint64_t)d->vv_weights; *vv_pitch = (fem_uint)d->nbr_pitch;
+  *vws_pitch = (fem_uint)d->vvw_pitch; *vv_size = d->W;
+  *grads = (uint64_t)d->he_grads; *he_pitch = (fem_uint)d->he_pitch;
+  *parts_n = (uint64_t)d->parts_n; *block_face_count = (uint64_t)d->bfc;
+  *blocks = (fem_uint)d->n; *threads = d->threads; *smem_size = d->smem;
+}
+
+// ---- native plan ------------------------------------------------------------
+
+void fem_plan_destroy(fem_plan *p) {
+  if (!p) return;
+  p->slice_off.release(); p->idx.release();
+  if (p->coef) (void)hipFree(p->coef);
+  for (void *s : p->state) if (s) (void)hipFree(s);
+  delete p;
+}
+
+int fem_plan_create(const fem_mesh *ordered, int precision, fem_plan **out) {
+  if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64))
+    return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
+  fem::SellLayout L;
+  int rc = fem::packSellLayout(ordered->mesh, ordered->stats, L);
+  if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh has no topology/stats or is too large");
+  fem_plan *p = new fem_plan();
+  p->precision = precision; p->V = L.V; p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4;
+  p->entries = L.idx.size();
+  const size_t sb = precision == FEM_PREC_F32 ? sizeof(float) : sizeof(double);
+  hipError_t e = hipSuccess;
+  auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+  ok(p->slice_off.alloc(L.slice_off.size())) && ok(p->slice_off.upload(L.slice_off.data())) &&
+  ok(p->idx.alloc(L.idx.size())) && ok(p->idx.upload(L.idx.data())) &&
+  ok(hipMalloc(&p->coef, 4 * sb * (p->entries ? p->entries : 1))) &&
+  ok(hipMalloc(&p->state[0], 2 * sb * p->V)) && ok(hipMalloc(&p->state[1], 2 * sb * p->V));
+  if (e == hipSuccess) {
+    if (precision == FEM_PREC_F32) {
+      std::vector<float> c32(L.coef.begin(), L.coef.end());
+      ok(hipMemcpy(p->coef, c32.data(), sizeof(float) * c32.size(), hipMemcpyHostToDevice));
+    } else {
+      ok(hipMemcpy(p->coef, L.coef.data(), sizeof(double) * L.coef.size(), hipMemcpyHostToDevice));
+    }
+    ok(hipMemset(p->state[0], 0, 2 * sb * p->V));
+    ok(hipMemset(p->state[1], 0, 2 * sb * p->V));
+  }
+  if (e != hipSuccess) { fem_plan_destroy(p); return fail(FEM_ERR_DEVICE, "fem_plan_create", e); }
+  *out = p;
+  return FEM_OK;
+}
+
+int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn) {
+  if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_set_state: null");
+  if (p->precision == FEM_PREC_F32) {
+    std::vector<float> h(2 * (size_t)p->V);
+    for (size_t i = 0; i < p->V; i++) { h[2 * i] = (float)nFn[i]; h[2 * i + 1] = (float)cFn[i]; }
+    HIP_TRY(hipMemcpy(p->state[p->cur], h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  } else {
+    std::vector<double> h(2 * (size_t)p->V);
+    for (size_t i = 0; i < p->V; i++) { h[2 * i] = nFn[i]; h[2 * i + 1] = cFn[i]; }
+    HIP_TRY(hipMemcpy(p->state[p->cur], h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+  }
+  return FEM_OK;
+}
+
+int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn) {
+  if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_get_state: null");
+  HIP_TRY(hipDeviceSynchronize());
+  if (p->precision == FEM_PREC_F32) {
+    std::vector<float> h(2 * (size_t)p->V);
+    HIP_TRY(hipMemcpy(h.data(), p->state[p->cur], sizeof(float) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < p->V; i++) { nFn[i] = h[2 * i]; cFn[i] = h[2 * i + 1]; }
+  } else {
+    std::vector<double> h(2 * (size_t)p->V);
+    HIP_TRY(hipMemcpy(h.data(), p->state[p->cur], sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < p->V; i++) { nFn[i] = h[2 * i]; cFn[i] = h[2 * i + 1]; }
+  }
+  return FEM_OK;
+}
+
+int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream) {
+  if (!p || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_plan_run: bad argument");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  for (int i = 0; i < nsteps; i++) {
+    void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
+    if (p->precision == FEM_PREC_F32) {
+      ModelT<float> m = {(float)model->nMax, (float)model->D, (float)model->r, (float)model->alpha, (float)model->S, (float)dt};
+      hipLaunchKernelGGL(sell_step_kernel<float>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
+                         (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
+                         p->V, p->nslices, p->nblocks, m);
+    } else {
+      ModelT<double> m = {model->nMax, model->D, model->r, model->alpha, model->S, dt};
+      hipLaunchKernelGGL(sell_step_kernel<double>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
+                         (const double2 *)src, (double2 *)dst, p->slice_off.p, p->idx.p, (const double4 *)p->coef,
+                         p->V, p->nslices, p->nblocks, m);
+    }
+    p->cur ^= 1;
+  }
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, int *scalar_bytes) {
+  if (!p) return fail(FEM_ERR_INVALID, "fem_plan_state: null");
+  if (dev_ptr) *dev_ptr = (uint64_t)p->state[p->cur];
+  if (n_vertices) *n_vertices = p->V;
+  if (scalar_bytes) *scalar_bytes = p->precision == FEM_PREC_F32 ? 4 : 8;
+  return FEM_OK;
+}
+
+uint64_t fem_plan_operator_bytes(const fem_plan *p) {
+  if (!p) return 0;
+  const size_t sb = p->precision == FEM_PREC_F32 ? 4 : 8;
+  return (uint64_t)p->entries * (4 + 4 * sb) + (uint64_t)(p->nslices + 1) * 4;
+}
+
+}  // extern "C"

@@ -1,0 +1,155 @@
+// mesh_stats.cpp -- host operator assembly (geometry -> weights) and the CPU
+// operators, on the build's own mesh type.
+// Follows reference src/mesh_function.cpp:27-67 (initMeshStats), :70-160
+// (angles/cot), :162-216 (areas), :219-271 (Laplacian weights), :310-350 (max
+// edge), :351-397 (gradient vectors) and src/mesh_function.h:6-110 (operators).
+#include <cmath>
+
+#include "fem_host.hpp"
+
+namespace fem {
+
+namespace {
+
+// geometry scalar: float reproduces the reference's Vec3f narrowing, double is
+// the all-fp64 variant
+template <typename G> struct Vec3 {
+  G x, y, z;
+  Vec3() : x(0), y(0), z(0) {}
+  Vec3(G a, G b, G c) : x(a), y(b), z(c) {}
+  explicit Vec3(const double *p) : x((G)p[0]), y((G)p[1]), z((G)p[2]) {}
+  Vec3 operator-(const Vec3 &o) const { return Vec3(x - o.x, y - o.y, z - o.z); }
+  Vec3 operator/(G s) const { return Vec3(x / s, y / s, z / s); }
+  G dot(const Vec3 &o) const { return x * o.x + y * o.y + z * o.z; }
+  Vec3 cross(const Vec3 &o) const { return Vec3(y * o.z - z * o.y, z * o.x - x * o.z, x * o.y - y * o.x); }
+  G norm() const { return std::sqrt(dot(*this)); }
+};
+
+template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
+  const int V = (int)m.n_vertices(), F = (int)m.n_faces(), H = m.H, H3 = 3 * F;
+  const double *P = m.points.data();
+  s.meshAngle.assign(H, 0.0); s.meshCot.assign(H, 0.0);
+  s.meshArea.assign(F, 0.0); s.areaPerVtx.assign(V, 0.0);
+  s.wHej.assign(H, 0.0); s.wVtx.assign(V, 0.0);
+  s.gradVec12.assign(3 * (size_t)F, 0.0); s.gradVec13.assign(3 * (size_t)F, 0.0);
+
+  // per face: the three corner angles (angle at the to-vertex of each of its
+  // half-edges), cotangents, area, hat-function gradients
+  for (int f = 0; f < F; f++) {
+    const uint ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
+    const Vec3<G> pa(P + 3 * ia), pb(P + 3 * ib), pc(P + 3 * ic);
+    const Vec3<G> corner[3] = {pa, pb, pc};
+    for (int k = 0; k < 3; k++) {                       // h = 3f+k : corner k -> corner k+1
+      const Vec3<G> &p1 = corner[k], &p2 = corner[(k + 1) % 3], &p3 = corner[(k + 2) % 3];
+      Vec3<G> v21 = p1 - p2, v23 = p3 - p2;
+      G d = v21.dot(v23 / (v21.norm() * v23.norm()));   // precedence of mesh_function.cpp:126
+      double ang = std::acos(d);                        // acos(float) for G = float
+      s.meshAngle[3 * f + k] = ang;
+      s.meshCot[3 * f + k] = 1. / std::tan(ang);
+    }
+    // (v1, v2, v3) = (c, a, b)
+    Vec3<G> v21 = pc - pa, v23 = pb - pa;
+    double area = v21.cross(v23).norm() / 2;
+    s.meshArea[f] = area;
+    s.areaPerVtx[ic] += area / 3; s.areaPerVtx[ia] += area / 3; s.areaPerVtx[ib] += area / 3;
+
+    // face normal from the double points, narrowed, re-normalised in G
+    double e1[3], e2[3];
+    for (int k = 0; k < 3; k++) { e1[k] = P[3 * ic + k] - P[3 * ib + k]; e2[k] = P[3 * ia + k] - P[3 * ib + k]; }
+    double nd[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    double nl = std::sqrt(nd[0] * nd[0] + nd[1] * nd[1] + nd[2] * nd[2]);
+    Vec3<G> N((G)(nl != 0 ? nd[0] / nl : 0.0), (G)(nl != 0 ? nd[1] / nl : 0.0), (G)(nl != 0 ? nd[2] / nl : 0.0));
+    G gl = N.norm();
+    if (gl != 0) N = N / gl;
+    const G twoA = (G)(2 * area);
+    Vec3<G> g12 = N.cross(pc - pb) / twoA;              // N x (pt1 - pt3)
+    Vec3<G> g13 = N.cross(pa - pc) / twoA;              // N x (pt2 - pt1)
+    s.gradVec12[3 * f] = g12.x; s.gradVec12[3 * f + 1] = g12.y; s.gradVec12[3 * f + 2] = g12.z;
+    s.gradVec13[3 * f] = g13.x; s.gradVec13[3 * f + 1] = g13.y; s.gradVec13[3 * f + 2] = g13.z;
+  }
+
+  // cot-Laplacian rows scaled by the inverse lumped mass
+  for (int h = 0; h < H; h++) {
+    const int ho = m.opp[h];
+    double wg = 0;
+    if (h < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(h)];
+    if (ho < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(ho)];
+    const uint v1 = m.he_from[h];
+    s.wHej[h] = wg / (2 * s.areaPerVtx[v1]);
+    s.wVtx[v1] -= s.wHej[h];
+  }
+
+  double mx = 0;
+  for (int h = 0; h < H; h++) {
+    double len = (Vec3<G>(P + 3 * m.he_from[h]) - Vec3<G>(P + 3 * m.he_to[h])).norm();
+    if (len > mx) mx = len;
+  }
+  s.maxEdgeLen = mx;
+}
+
+}  // namespace
+
+void initMeshStats(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision) {
+  if (ipMesh.H == 0) ipMesh.update_topology();
+  mStats.precision = precision;
+  if (precision == FEM_PREC_F64) assemble<double>(ipMesh, mStats);
+  else assemble<float>(ipMesh, mStats);
+}
+
+void deleteMeshStats(MeshStats &mStats) { mStats = MeshStats(); }
+
+bool computeLaplacianCPU(const SimpleTriMesh &m, const double *fn, double *lap, const double *wHej,
+                         const double *wVtx) {
+  const int V = (int)m.n_vertices();
+  for (int i = 0; i < V; i++) {
+    double acc = fn[i] * wVtx[i];
+    for (int e = m.rowptr[i]; e < m.rowptr[i + 1]; e++) acc += fn[m.col[e]] * wHej[m.row_he[e]];
+    lap[i] = acc;
+  }
+  return true;
+}
+
+template <typename G>
+static void faceGradients(const SimpleTriMesh &m, const double *g12, const double *g13, double *out,
+                          const double *fn) {
+  const int F = (int)m.n_faces();
+  for (int f = 0; f < F; f++) {
+    const uint v1 = m.faces[3 * f + 2], v2 = m.faces[3 * f], v3 = m.faces[3 * f + 1];
+    const G d12 = (G)(fn[v2] - fn[v1]), d13 = (G)(fn[v3] - fn[v1]);
+    for (int k = 0; k < 3; k++) out[3 * f + k] = (G)g12[3 * f + k] * d12 + (G)g13[3 * f + k] * d13;
+  }
+}
+
+bool computeFaceGradientsCPU(const SimpleTriMesh &m, const double *gradV12, const double *gradV13,
+                             double *opGrad, const double *fn, int precision) {
+  if (precision == FEM_PREC_F64) faceGradients<double>(m, gradV12, gradV13, opGrad, fn);
+  else faceGradients<float>(m, gradV12, gradV13, opGrad, fn);
+  return true;
+}
+
+template <typename G>
+static void vertexGradients(const SimpleTriMesh &m, const double *fg, double *out, const double *ang) {
+  const int V = (int)m.n_vertices(), H3 = 3 * (int)m.n_faces();
+  for (int v = 0; v < V; v++) {
+    G g[3] = {0, 0, 0};
+    double wg = 0;
+    for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+      const int h = m.row_he[e];
+      if (h >= H3) continue;
+      const int hp = SimpleTriMesh::prev_halfedge(h);
+      const G a = (G)ang[hp];
+      for (int k = 0; k < 3; k++) g[k] += (G)fg[3 * (h / 3) + k] * a;
+      wg += ang[hp];
+    }
+    for (int k = 0; k < 3; k++) out[3 * v + k] = wg > 0 ? (double)(g[k] / (G)wg) : 0.0;
+  }
+}
+
+bool computeVertexGradientsCPU(const SimpleTriMesh &m, const double *faceGrad, double *opVtxGrad,
+                               const double *meshAngles, int precision) {
+  if (precision == FEM_PREC_F64) vertexGradients<double>(m, faceGrad, opVtxGrad, meshAngles);
+  else vertexGradients<float>(m, faceGrad, opVtxGrad, meshAngles);
+  return true;
+}
+
+}  // namespace fem

@@ -1,0 +1,163 @@
+// pack.cpp -- device-layout packing.
+//   packRefLayout : the reference's padded SoA arrays, initializeGPUData,
+//                   reference src/main.cpp:207-342 (index formulas: SURVEY.md App. A)
+//   packSellLayout: the native layout -- sliced ELL, 64 rows per slice, the
+//                   vertex-gradient operator folded into per-nonzero 3-vectors
+#include <algorithm>
+#include <cstring>
+
+#include "fem_host.hpp"
+
+namespace fem {
+
+int packRefLayout(const SimpleTriMesh &m, const MeshStats &s, int n, const uint *node_parts,
+                  const uint *element_parts, RefLayout &o) {
+  const uint V = m.n_vertices(), F = m.n_faces();
+  if (m.H == 0 || s.precision < 0 || n < 1) return FEM_ERR_INVALID;
+  if (node_parts[0] != 0 || node_parts[n] != V || element_parts[n + 1] != F) return FEM_ERR_INVALID;
+  o = RefLayout();
+  o.n = n;
+
+  // halo faces (main.cpp:209-232): faces touching a partition's vertices but
+  // outside its own face range, ascending and unique per partition
+  std::vector<int32_t> vfPtr(V + 2, 0);
+  for (size_t i = 0; i < 3 * (size_t)F; i++) vfPtr[m.faces[i] + 2]++;
+  for (uint i = 0; i < V; i++) vfPtr[i + 2] += vfPtr[i + 1];
+  std::vector<uint> vf(3 * (size_t)F);
+  for (size_t i = 0; i < 3 * (size_t)F; i++) vf[vfPtr[m.faces[i] + 1]++] = (uint)(i / 3);
+  o.halo_faces_keys.assign(n + 1, 0);
+  for (int p = 0; p < n; p++) {
+    if (node_parts[p + 1] < node_parts[p] || element_parts[p + 1] < element_parts[p]) return FEM_ERR_INVALID;
+    const size_t start = o.halo_faces.size();
+    for (uint j = node_parts[p]; j < node_parts[p + 1]; j++)
+      for (int e = vfPtr[j]; e < vfPtr[j + 1]; e++) {
+        const uint f = vf[e];
+        if (f < element_parts[p] || f >= element_parts[p + 1]) o.halo_faces.push_back(f);
+      }
+    std::sort(o.halo_faces.begin() + start, o.halo_faces.end());
+    o.halo_faces.erase(std::unique(o.halo_faces.begin() + start, o.halo_faces.end()), o.halo_faces.end());
+    o.halo_faces_keys[p + 1] = (uint)o.halo_faces.size();
+  }
+
+  // sizes (main.cpp:241-250,261-270,290-294)
+  o.block_face_count.resize(n);
+  for (int p = 0; p < n; p++) {
+    o.block_face_count[p] = element_parts[p + 1] - element_parts[p] + o.halo_faces_keys[p + 1] - o.halo_faces_keys[p];
+    o.max_vertex_count = std::max(o.max_vertex_count, node_parts[p + 1] - node_parts[p]);
+    o.max_face_count = std::max(o.max_face_count, o.block_face_count[p]);
+  }
+  for (uint v = 0; v < V; v++) o.vv_max_neighbors = std::max(o.vv_max_neighbors, (uint)(m.rowptr[v + 1] - m.rowptr[v]));
+  const size_t maxV = o.max_vertex_count, W = o.vv_max_neighbors, maxF = o.max_face_count;
+
+  o.vertex_weights.assign((size_t)n * maxV, 0.0);
+  o.nbr_v.assign((size_t)n * (W + 1) * maxV, 0u);
+  o.vv_weights.assign((size_t)n * W * maxV, 0.0);
+  o.face_vertices.assign((size_t)n * 3 * maxF, 0u);
+  o.fv_weights_new.assign((size_t)n * 3 * maxF, 0.0);
+  fem_float4 zero4 = {0, 0, 0, 0};
+  o.he_grads.assign((size_t)n * 2 * maxF, zero4);
+
+  for (int p = 0; p < n; p++) {
+    // vertices: diagonal weight + ELL row (main.cpp:252-287)
+    for (uint j = 0; j < node_parts[p + 1] - node_parts[p]; j++) {
+      const uint v = node_parts[p] + j;
+      o.vertex_weights[(size_t)p * maxV + j] = s.wVtx[v];
+      uint counter = 0;
+      for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++, counter++) {
+        o.nbr_v[(size_t)p * (W + 1) * maxV + (size_t)(counter + 1) * maxV + j] = m.col[e];
+        o.vv_weights[(size_t)p * W * maxV + (size_t)counter * maxV + j] = s.wHej[m.row_he[e]];
+      }
+      o.nbr_v[(size_t)p * (W + 1) * maxV + j] = counter;
+    }
+    // faces: interior first, then halo (main.cpp:299-338)
+    const uint nint = element_parts[p + 1] - element_parts[p];
+    for (uint slot = 0; slot < o.block_face_count[p]; slot++) {
+      const uint f = slot < nint ? element_parts[p] + slot : o.halo_faces[o.halo_faces_keys[p] + (slot - nint)];
+      fem_float4 &g12 = o.he_grads[(size_t)p * 2 * maxF + slot];
+      fem_float4 &g13 = o.he_grads[(size_t)p * 2 * maxF + maxF + slot];
+      g12.x = (float)s.gradVec12[3 * f]; g12.y = (float)s.gradVec12[3 * f + 1]; g12.z = (float)s.gradVec12[3 * f + 2];
+      g13.x = (float)s.gradVec13[3 * f]; g13.y = (float)s.gradVec13[3 * f + 1]; g13.z = (float)s.gradVec13[3 * f + 2];
+      for (int c = 0; c < 3; c++) {   // fh iteration yields to-vertices a, b, c; its half-edge ends there
+        o.face_vertices[(size_t)p * 3 * maxF + (size_t)c * maxF + slot] = m.faces[3 * f + c];
+        o.fv_weights_new[(size_t)p * 3 * maxF + (size_t)c * maxF + slot] = s.meshAngle[3 * f + (c + 2) % 3];
+      }
+    }
+  }
+  return FEM_OK;
+}
+
+// Native layout.  Row v, entry for neighbour j (half-edge h: v -> j):
+//   w     = wHej[h]                                  (Laplacian, difference form)
+//   C_vj  = (1/Theta_v) * sum over the <=2 faces f on edge (v,j) of
+//           theta_{v,f} * grad(phi_j) on f           (vertex gradient, folded)
+// so that  lap f (v) = sum_j w (f_j - f_v)  and  G f (v) = sum_j C_vj (f_j - f_v),
+// which equal the reference's fn*wVtx + sum fn_j*wHej (wVtx = -sum wHej,
+// mesh_function.cpp:263-265) and its angle-weighted mean of face gradients
+// (mesh_function.h:35-110) because the hat gradients of a face sum to zero.
+// Rows are padded to the slice width with (idx = own row, coef = 0).
+int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o) {
+  const uint V = m.n_vertices();
+  const int H3 = 3 * (int)m.n_faces();
+  if (m.H == 0 || s.precision < 0 || V == 0) return FEM_ERR_INVALID;
+  o = SellLayout();
+  o.V = V;
+  o.nslices = (V + 63) / 64;
+  o.slice_off.assign(o.nslices + 1, 0);
+  for (uint sl = 0; sl < o.nslices; sl++) {
+    uint w = 0;
+    for (uint v = sl * 64; v < std::min(V, sl * 64 + 64); v++) w = std::max(w, (uint)(m.rowptr[v + 1] - m.rowptr[v]));
+    uint64_t next = (uint64_t)o.slice_off[sl] + (uint64_t)w * 64;
+    if (next > 0xffffffffull) return FEM_ERR_LIMIT;
+    o.slice_off[sl + 1] = (uint)next;
+  }
+  const size_t entries = o.slice_off[o.nslices];
+  o.idx.resize(entries);
+  o.coef.assign(4 * entries, 0.0);
+
+  auto hatGrad = [&](int f, int corner, double *g) {   // corner 0 (a): gradVec12, 1 (b): gradVec13, 2 (c): -(both)
+    for (int k = 0; k < 3; k++) {
+      const double g12 = s.gradVec12[3 * (size_t)f + k], g13 = s.gradVec13[3 * (size_t)f + k];
+      g[k] = corner == 0 ? g12 : (corner == 1 ? g13 : -(g12 + g13));
+    }
+  };
+
+  for (uint sl = 0; sl < o.nslices; sl++) {
+    const uint off = o.slice_off[sl], width = (o.slice_off[sl + 1] - off) / 64;
+    for (uint lane = 0; lane < 64; lane++) {
+      const uint v = sl * 64 + lane;
+      const uint self = v < V ? v : V - 1;
+      for (uint k = 0; k < width; k++) o.idx[off + (size_t)k * 64 + lane] = self;
+      if (v >= V) continue;
+      double theta = 0;
+      for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+        const int h = m.row_he[e];
+        if (h < H3) theta += s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
+      }
+      uint k = 0;
+      for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++, k++) {
+        const int h = m.row_he[e], ho = m.opp[h];
+        double C[3] = {0, 0, 0}, g[3];
+        if (theta > 0) {
+          if (h < H3) {           // face left of v->j: v = corner h%3, j = next corner
+            hatGrad(h / 3, (h % 3 + 1) % 3, g);
+            const double a = s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
+            for (int d = 0; d < 3; d++) C[d] += a * g[d];
+          }
+          if (ho < H3) {          // face left of j->v: j = corner ho%3, angle at v = meshAngle[ho]
+            hatGrad(ho / 3, ho % 3, g);
+            const double a = s.meshAngle[ho];
+            for (int d = 0; d < 3; d++) C[d] += a * g[d];
+          }
+          for (int d = 0; d < 3; d++) C[d] /= theta;
+        }
+        const size_t pos = off + (size_t)k * 64 + lane;
+        o.idx[pos] = m.col[e];
+        o.coef[4 * pos] = s.wHej[h];
+        o.coef[4 * pos + 1] = C[0]; o.coef[4 * pos + 2] = C[1]; o.coef[4 * pos + 3] = C[2];
+      }
+    }
+  }
+  return FEM_OK;
+}
+
+}  // namespace fem

@@ -1,0 +1,222 @@
+/*
+ * fem_hip.h -- C-ABI of the MI355X-native FEM hot path (libfem_hip.so).
+ *
+ * Plain C: no HIP/CUDA headers, no C++ types.  Every entry point cites the
+ * interface of the reference (Blue-Robot/FEM, paths under its src/) that it
+ * replaces.  Pointers named dev_* / documented "device" are HIP device
+ * pointers; everything else is host memory.  All functions returning int
+ * return FEM_OK (0) or a negative fem_status; none aborts.
+ */
+#ifndef FEM_HIP_H
+#define FEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef unsigned int fem_uint;                       /* the reference's `uint` */
+
+/* Layout-identical stand-ins for CUDA's double2 / float4 (FEM_common.h:3-25). */
+typedef struct __attribute__((aligned(16))) { double x, y; } fem_double2;
+typedef struct __attribute__((aligned(16))) { float x, y, z, w; } fem_float4;
+
+/* Model constants.  The reference compiles them into the .cu
+ * (FEM_common.cu:9-13); here they are data.  fem_default_model() gives that
+ * set: nMax=1, D=0.25, r=59.4537909143081, alpha=269, S=1. */
+typedef struct { double nMax, D, r, alpha, S; } fem_model;
+
+typedef enum {
+  FEM_OK = 0,
+  FEM_ERR_INVALID = -1,      /* bad argument / inconsistent sizes          */
+  FEM_ERR_LIMIT = -2,        /* partition exceeds a kernel limit           */
+  FEM_ERR_DEVICE = -3,       /* HIP runtime error (see fem_error_detail)   */
+  FEM_ERR_ALLOC = -4,
+  FEM_ERR_IO = -5,
+  FEM_ERR_NONMANIFOLD = -6   /* a directed edge occurs twice               */
+} fem_status;
+
+#define FEM_PREC_MIXED 0     /* the reference's float/double mix           */
+#define FEM_PREC_F64 1       /* all double                                 */
+#define FEM_PREC_F32 2       /* native fp32 state + operator (plans only)  */
+
+void fem_default_model(fem_model *m);
+const char *fem_error_string(int status);
+/* status of the last failing call on this thread (the `void step` shim has no
+ * other way to report one) and the HIP error text that came with it */
+int fem_last_error(void);
+const char *fem_error_detail(void);
+void fem_free(void *p);      /* frees arrays returned through T** out-params */
+
+/* ------------------------------------------------------------------ */
+/* 1. The device step: the reference's own symbol.                      */
+/* ------------------------------------------------------------------ */
+
+/* Replaces `extern "C" void step(...)`, FEM_common.h:3-25 / FEM_common.cu:168-180.
+ * Same name, argument order and meaning: device pointers laid out as
+ * main.cpp:207-342 packs them, byte pitches as
+ * cudaMallocPitch/cudaMalloc3D returned them, blocks = number of partitions.
+ * `threads` and `smem_size` are accepted and ignored (the kernel picks its
+ * own wave64 geometry).  Asynchronous on the default stream; constants =
+ * fem_default_model().  Errors: fem_last_error(). */
+void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
+          fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
+          fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
+          fem_uint vws_pitchInBytes, fem_uint vv_size, fem_float4 *grads,
+          fem_uint he_pitchInBytes, fem_uint *parts_n, fem_uint *block_face_count,
+          fem_uint blocks, fem_uint threads, double dt, fem_uint smem_size);
+
+/* The same launch with a status, explicit constants and stream (hipStream_t
+ * as void*; NULL = default stream).  max_part_vertices = the largest
+ * partition (sizes the LDS accumulators, main.cpp:369); 0 = derive it from
+ * smem_size as the reference caller computed it (smem_size / 32). */
+int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
+             fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
+             fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
+             fem_uint vws_pitchInBytes, fem_uint vv_size, fem_float4 *grads,
+             fem_uint he_pitchInBytes, fem_uint *parts_n, fem_uint *block_face_count,
+             fem_uint blocks, double dt, fem_uint max_part_vertices, const fem_model *model,
+             void *stream);
+
+/* ------------------------------------------------------------------ */
+/* 2. Host interfaces the path keeps.                                   */
+/* ------------------------------------------------------------------ */
+
+/* .off / COFF load; replaces loadMesh -> OpenMesh::IO::read_mesh, main.cpp:156-167.
+ * rgb (3 bytes per vertex) is NULL when the file has no colours.  Arrays are
+ * malloc'ed; release with fem_free. */
+int fem_off_read(const char *path, int *V, int *F, double **points, fem_uint **tri,
+                 unsigned char **rgb);
+/* COFF writer ("visualisation output" without GL; file shape of
+ * ResultantPattern.off:1-4).  rgb may be NULL (plain OFF). */
+int fem_off_write(const char *path, int V, int F, const double *points, const fem_uint *tri,
+                  const unsigned char *rgb);
+
+/* Synthetic inputs (no counterpart in the reference; BASELINE.md workloads):
+ * class-I geodesic icosahedron of frequency nu (V = 10 nu^2 + 2, F = 20 nu^2)
+ * scaled so the mean edge length is `edge`; and the nx x ny strip with the
+ * connectivity and 45-degree tilt of ResultantPattern.off (nx=11, ny=41,
+ * h=0.1 reproduces its geometry). */
+int fem_make_icosphere(int nu, double edge, int *V, int *F, double **points, fem_uint **tri);
+int fem_make_strip(int nx, int ny, double h, int *V, int *F, double **points, fem_uint **tri);
+
+/* Initial condition of initializeData, main.cpp:178-186, with rand() replaced
+ * by an explicit Lehmer generator (x <- 48271 x mod 2^31-1) seeded by `seed`. */
+void fem_initial_condition(int V, fem_uint seed, double nMax, double *nFn, double *cFn);
+
+/* Mesh handle = points + faces + the half-edge tables OpenMesh would hold. */
+typedef struct fem_mesh fem_mesh;
+int fem_mesh_create(int V, int F, const double *points, const fem_uint *tri, fem_mesh **out);
+void fem_mesh_destroy(fem_mesh *m);
+void fem_mesh_counts(const fem_mesh *m, int *V, int *F, int *H);
+void fem_mesh_arrays(const fem_mesh *m, const double **points, const fem_uint **tri);
+/* half-edge tables: opp/he_from/he_to [H]; CSR rows of outgoing half-edges
+ * (ascending neighbour id): rowptr [V+1], col/row_he [H] */
+void fem_mesh_topology(const fem_mesh *m, const int32_t **opp, const fem_uint **he_from,
+                       const fem_uint **he_to, const int32_t **rowptr, const fem_uint **col,
+                       const int32_t **row_he);
+
+/* Replaces `extern "C" int partition(SimpleTriMesh, SimpleTriMesh*, uint**,
+ * uint**, int)`, partitioning_common.h:3-9 / partitioning_common.cpp:21-30, in
+ * flat-array form.  Outputs: perm_v[V], perm_f[F] (new position of each old
+ * index), node_parts[n+1], element_parts[n+2] (last bucket = cut faces), and
+ * the reordered mesh.  Returns the edge cut (>= 0) or a negative fem_status.
+ * METIS is replaced by a deterministic Hilbert-curve k-way split. */
+int fem_partition(const fem_mesh *original, int n, int64_t *perm_v, int64_t *perm_f,
+                  fem_uint *node_parts, fem_uint *element_parts, fem_mesh **ordered);
+/* The stage METIS_PartMeshDual occupied (partitioning_common.cpp:51-58):
+ * vertex -> part id in [0,n). */
+int fem_partition_vertices(const fem_mesh *m, int n, int64_t *npart);
+/* The deterministic stage after it (partitioning_common.cpp:78-176), given any
+ * npart[]: same outputs as fem_partition. */
+int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,
+                        int64_t *perm_f, fem_uint *node_parts, fem_uint *element_parts,
+                        fem_mesh **ordered);
+
+/* Replaces initMeshStats(mesh, MeshStats&), mesh_function.cpp:27-67 (hot
+ * fields of MeshStats, common.h:19-38).  precision = FEM_PREC_MIXED or
+ * FEM_PREC_F64.  Arrays stay owned by the mesh handle. */
+int fem_mesh_init_stats(fem_mesh *m, int precision);
+int fem_mesh_stats(const fem_mesh *m, const double **meshAngle, const double **meshCot,
+                   const double **meshArea, const double **areaPerVtx, const double **wHej,
+                   const double **wVtx, double *maxEdgeLen, const double **gradVec12,
+                   const double **gradVec13);
+
+/* CPU operators kept by name (mesh_function.h:6-110), on the mesh handle. */
+int fem_compute_laplacian_cpu(const fem_mesh *m, const double *fn, double *lap);
+int fem_compute_face_gradients_cpu(const fem_mesh *m, const double *fn, double *faceGrad /*3F*/);
+int fem_compute_vertex_gradients_cpu(const fem_mesh *m, const double *faceGrad, double *vtxGrad /*3V*/);
+
+/* ------------------------------------------------------------------ */
+/* 3. Reference device layout + harness (initializeGPUData / GPUrun).   */
+/* ------------------------------------------------------------------ */
+
+/* Replaces initializeGPUData, main.cpp:207-342: halo faces + padded SoA
+ * arrays, on an ordered mesh whose stats are initialised. */
+typedef struct fem_ref_layout fem_ref_layout;
+int fem_ref_layout_create(const fem_mesh *ordered, int n, const fem_uint *node_parts,
+                          const fem_uint *element_parts, fem_ref_layout **out);
+void fem_ref_layout_destroy(fem_ref_layout *l);
+void fem_ref_layout_sizes(const fem_ref_layout *l, fem_uint *max_vertex_count,
+                          fem_uint *vv_max_neighbors, fem_uint *max_face_count,
+                          fem_uint *n_halo_faces);
+void fem_ref_layout_arrays(const fem_ref_layout *l, const fem_uint **halo_faces_keys,
+                           const fem_uint **halo_faces, const fem_uint **block_face_count,
+                           const double **vertex_weights, const fem_uint **nbr_v,
+                           const double **vv_weights, const fem_uint **face_vertices,
+                           const double **fv_weights_new, const fem_float4 **he_grads);
+
+/* Replaces the allocation/upload/limit-check part of GPUrun, main.cpp:344-452:
+ * pitched device copies of a layout plus two double2 state buffers. */
+typedef struct fem_ref_device fem_ref_device;
+int fem_ref_device_create(const fem_ref_layout *l, const fem_uint *node_parts, int V,
+                          fem_ref_device **out);
+void fem_ref_device_destroy(fem_ref_device *d);
+int fem_ref_device_set_state(fem_ref_device *d, const fem_double2 *fn);   /* H2D, main.cpp:451 */
+int fem_ref_device_get_state(fem_ref_device *d, fem_double2 *fn);         /* D2H, main.cpp:499  */
+/* nsteps ping-pong `step` launches (main.cpp:558-562), no host sync inside. */
+int fem_ref_device_run(fem_ref_device *d, int nsteps, double dt, const fem_model *model,
+                       void *stream);
+/* raw device pointers and pitches, for callers that invoke step() themselves;
+ * args21 receives, in step()'s order, the 17 pointer/pitch/size arguments that
+ * precede `blocks` as uint64 (pointers) */
+void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn_two,
+                         uint64_t *fv, uint64_t *fv_weights, fem_uint *fv_pitch,
+                         fem_uint *fvw_pitch, uint64_t *nbr, uint64_t *vtxW, fem_uint *vw_pitch,
+                         uint64_t *vertex_weights, fem_uint *vv_pitch, fem_uint *vws_pitch,
+                         fem_uint *vv_size, uint64_t *grads, fem_uint *he_pitch,
+                         uint64_t *parts_n, uint64_t *block_face_count, fem_uint *blocks,
+                         fem_uint *threads, fem_uint *smem_size);
+
+/* ------------------------------------------------------------------ */
+/* 4. Native plan: the MI355X layout of the same operator.              */
+/* ------------------------------------------------------------------ */
+
+/* One plan = the assembled operator of an ordered mesh in the native device
+ * layout (sliced ELL, 64-row slices, folded gradient coefficients)
+ * plus two ping-pong state buffers.  Replaces initializeGPUData + GPUrun's
+ * allocations for callers that do not need the reference's array shapes.
+ * precision = FEM_PREC_F32 or FEM_PREC_F64.  Vertices [own_begin, own_end)
+ * are advanced by this plan; the others are ghosts whose state the caller
+ * refreshes between steps (multi-GPU shards).  own_begin=0, own_end=V for a
+ * whole mesh. */
+typedef struct fem_plan fem_plan;
+int fem_plan_create(const fem_mesh *ordered, int precision, fem_plan **out);
+void fem_plan_destroy(fem_plan *p);
+int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn);
+int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn);
+/* nsteps explicit Euler steps, ping-ponging the plan's two buffers; async on
+ * `stream`.  One call = the reference's timed loop body (main.cpp:558-562). */
+int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream);
+/* device pointer of the current state buffer (interleaved (n,c) pairs of the
+ * plan's scalar type), its element count, and bytes per scalar */
+int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, int *scalar_bytes);
+/* operator footprint in device memory (bytes read per step, excluding state) */
+uint64_t fem_plan_operator_bytes(const fem_plan *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEM_HIP_H */
