@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py -- DOF-iterations/s of the explicit time-step loop (BASELINE.json metric).
+
+One "step" = one explicit Euler time step of the whole mesh (one `step` call in the
+reference, src/FEM_common.cu:168-180; timing protocol of src/main.cpp:547-567: warm-up
+steps, then back-to-back launches with no host sync inside, device-event timed).
+
+  python bench.py --gpus 1 --steps K --warmup W [--workload sphere16m|sphere1m|sphere10k]
+
+Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+WORKLOADS = {                       # class-I geodesic spheres, edge ~ 0.1
+    "sphere10k": dict(nu=32, verts_per_part=197),        # config 1 size (P = 52)
+    "sphere1m": dict(nu=320, verts_per_part=256),        # config 2
+    "sphere4m": dict(nu=640, verts_per_part=256),
+    "sphere16m": dict(nu=1280, verts_per_part=256),      # config 3 / north-star roofline size
+}
+ALG_BYTES_PER_VERTEX_STEP = 168     # V*24 + nnz*8 + F*48 on a closed genus-0 mesh
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """the oracle (serial C port of CPUrun) timed on this host, on a bounded sample of the
+    workload: the nu=320 sphere (1 024 002 vertices), as many steps as fit the budget"""
+    import fem_amd as fa
+    import oracle_lib as ol
+    nu = 320
+    pts, tri = fa.make_icosphere(nu, 0.1)
+    topo = ol.Topology(len(pts), tri)
+    st = ol.Stats(topo, pts, ol.F64)
+    n, c = ol.initial_condition(topo.V, 1)
+    dt = 0.1 * st.maxEdgeLen ** 2
+    model = fa.default_model().as_array()
+    t0 = time.perf_counter()
+    st.step(n, c, dt, 1, model)
+    one = time.perf_counter() - t0
+    steps = max(2, min(200, int(seconds_budget / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    st.step(n, c, dt, steps, model)
+    el = time.perf_counter() - t0
+    return {"value": 2.0 * topo.V * steps / el, "unit": "DOF-iterations/s", "cores": 1, "kind": "port",
+            "sample": "oracle fo_step_f64 (serial C), nu=320 icosphere V=%d, %d steps, %.1f s" % (topo.V, steps, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("FEM_BENCH_WORKLOAD", "sphere16m"), choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import fem_amd as fa
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    t_host = time.perf_counter()
+    pts, tri = fa.make_icosphere(wl["nu"], 0.1)
+    mesh = fa.Mesh(pts, tri)
+    V_total = mesh.V
+    nparts = max(world, V_total // wl["verts_per_part"])
+    if world > 1:
+        from fem_amd import dist as fdist
+        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision)
+    else:
+        from fem_amd import dist as fdist
+        runner = fdist.SingleRun(mesh, nparts, args.precision)
+    del pts, tri, mesh
+    t_host = time.perf_counter() - t_host
+
+    stream = torch.cuda.current_stream()
+    runner.run(args.warmup, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    runner.run(args.steps, stream)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        ms_per_step = wall * 1e3 / args.steps
+        kernel_ms = dev_ms / args.steps                     # average launch duration, device events
+        v_per_launch = runner.vertices_per_launch           # owned vertices this rank advances per launch
+        achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch / (kernel_ms * 1e-3) / 1e9
+        out = {
+            "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "%s: class-I geodesic icosphere nu=%d, V=%d, F=%d, %d partitions, "
+                                   "reaction-diffusion explicit Euler, seeded random IC"
+                                   % (args.workload, wl["nu"], V_total, 2 * V_total - 4, nparts),
+                       "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
+                       "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange" % world},
+            "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": runner.measured_traffic(),
+                         "alg_bytes_per_vertex_step": ALG_BYTES_PER_VERTEX_STEP, "avg_launch_ms": kernel_ms,
+                         "layout_bytes_per_launch": runner.layout_bytes_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

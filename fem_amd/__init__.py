@@ -320,9 +320,10 @@ def step(a, src, dst, dt):
 class Plan:
     """Native plan: sliced-ELL operator + ping-pong state on the device."""
 
-    def __init__(self, ordered, precision=PREC_F32):
+    def __init__(self, ordered, precision=PREC_F32, model=None):
         h = vp()
-        _check(lib.fem_plan_create(ordered.h, C.c_int(precision), C.byref(h)))
+        mp = C.byref(model) if model is not None else None
+        _check(lib.fem_plan_create(ordered.h, C.c_int(precision), mp, C.byref(h)))
         self.h, self.V, self.precision = h, ordered.V, precision
 
     def __del__(self):
@@ -347,6 +348,6 @@ class Plan:
         return lib.fem_plan_operator_bytes(self.h)
 
     def state_ptr(self):
-        p, nv, sb = C.c_uint64(), C.c_uint64(), C.c_int()
-        _check(lib.fem_plan_state(self.h, C.byref(p), C.byref(nv), C.byref(sb)))
-        return p.value, nv.value, sb.value
+        p, nv, sb, bn, bc = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_double(), C.c_double()
+        _check(lib.fem_plan_state(self.h, C.byref(p), C.byref(nv), C.byref(sb), C.byref(bn), C.byref(bc)))
+        return p.value, nv.value, sb.value, bn.value, bc.value

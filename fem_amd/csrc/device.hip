@@ -145,7 +145,8 @@ template <typename T> struct Vec;
 template <> struct Vec<float> { typedef float2 t2; typedef float4 t4; };
 template <> struct Vec<double> { typedef double2 t2; typedef double4 t4; };
 
-template <typename T> struct ModelT { T nMax, D, r, alpha, S, dt; };
+// bn = base value the stored n is a deviation from; cden = 1/(1+bn); nMaxOff = nMax - bn
+template <typename T> struct ModelT { T nMaxOff, D, r, alpha, S, dt, bn, cden; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void sell_step_kernel(
@@ -176,12 +177,17 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
     gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
     gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
   }
+  // The buffers hold deviations (n - bn, c - bn/(1+bn)) from the homogeneous state: differences
+  // are unchanged, n(nMax - n) = n((nMax - bn) - dev) and n/(1+n) - c = dev_n/((1+n)(1+bn)) - dev_c
+  // are exact rewrites, and the update no longer rounds at the magnitude of n itself.
+  const T n = m.bn + s.x;
   const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
-  const T dauN = m.D * lapn - m.alpha * s.x * lapc - m.alpha * dotP + m.S * m.r * s.x * (m.nMax - s.x);
-  const T dauC = lapc + m.S * (s.x / (1 + s.x) - s.y);
+  const T dauN = m.D * lapn - m.alpha * n * lapc - m.alpha * dotP + m.S * m.r * n * (m.nMaxOff - s.x);
+  const T dauC = lapc + m.S * (s.x * m.cden / (1 + n) - s.y);
+  const T un = m.dt * dauN + s.x, uc = m.dt * dauC + s.y;
   T2 o;
-  o.x = m.dt * dauN + s.x > 0 ? m.dt * dauN + s.x : (T)0;
-  o.y = m.dt * dauC + s.y > 0 ? m.dt * dauC + s.y : (T)0;
+  o.x = un + m.bn > 0 ? un : -m.bn;                 // max(0, n) of FEM_common.cu:164-165
+  o.y = uc + m.bn * m.cden > 0 ? uc : -(m.bn * m.cden);
   if (v < V) dst[v] = o;
 }
 
@@ -221,8 +227,9 @@ struct fem_plan {
   size_t entries = 0;
   DevBuf<fem_uint> slice_off, idx;
   void *coef = nullptr;            // float4 / double4 [entries]
-  void *state[2] = {nullptr, nullptr};
+  void *state[2] = {nullptr, nullptr};   // deviations from (base_n, base_c), interleaved
   int cur = 0;
+  double base_n = 1.0, base_c = 0.5;
 };
 
 extern "C" {
@@ -381,13 +388,17 @@ void fem_plan_destroy(fem_plan *p) {
   delete p;
 }
 
-int fem_plan_create(const fem_mesh *ordered, int precision, fem_plan **out) {
+int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out) {
   if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64))
     return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");
   fem::SellLayout L;
   int rc = fem::packSellLayout(ordered->mesh, ordered->stats, L);
   if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh has no topology/stats or is too large");
   fem_plan *p = new fem_plan();
+  p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
   p->precision = precision; p->V = L.V; p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4;
   p->entries = L.idx.size();
   const size_t sb = precision == FEM_PREC_F32 ? sizeof(float) : sizeof(double);
@@ -416,11 +427,11 @@ int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn) {
   if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_set_state: null");
   if (p->precision == FEM_PREC_F32) {
     std::vector<float> h(2 * (size_t)p->V);
-    for (size_t i = 0; i < p->V; i++) { h[2 * i] = (float)nFn[i]; h[2 * i + 1] = (float)cFn[i]; }
+    for (size_t i = 0; i < p->V; i++) { h[2 * i] = (float)(nFn[i] - p->base_n); h[2 * i + 1] = (float)(cFn[i] - p->base_c); }
     HIP_TRY(hipMemcpy(p->state[p->cur], h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
   } else {
     std::vector<double> h(2 * (size_t)p->V);
-    for (size_t i = 0; i < p->V; i++) { h[2 * i] = nFn[i]; h[2 * i + 1] = cFn[i]; }
+    for (size_t i = 0; i < p->V; i++) { h[2 * i] = nFn[i] - p->base_n; h[2 * i + 1] = cFn[i] - p->base_c; }
     HIP_TRY(hipMemcpy(p->state[p->cur], h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   }
   return FEM_OK;
@@ -432,11 +443,11 @@ int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn) {
   if (p->precision == FEM_PREC_F32) {
     std::vector<float> h(2 * (size_t)p->V);
     HIP_TRY(hipMemcpy(h.data(), p->state[p->cur], sizeof(float) * h.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < p->V; i++) { nFn[i] = h[2 * i]; cFn[i] = h[2 * i + 1]; }
+    for (size_t i = 0; i < p->V; i++) { nFn[i] = p->base_n + (double)h[2 * i]; cFn[i] = p->base_c + (double)h[2 * i + 1]; }
   } else {
     std::vector<double> h(2 * (size_t)p->V);
     HIP_TRY(hipMemcpy(h.data(), p->state[p->cur], sizeof(double) * h.size(), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < p->V; i++) { nFn[i] = h[2 * i]; cFn[i] = h[2 * i + 1]; }
+    for (size_t i = 0; i < p->V; i++) { nFn[i] = p->base_n + h[2 * i]; cFn[i] = p->base_c + h[2 * i + 1]; }
   }
   return FEM_OK;
 }
@@ -448,12 +459,14 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
     if (p->precision == FEM_PREC_F32) {
-      ModelT<float> m = {(float)model->nMax, (float)model->D, (float)model->r, (float)model->alpha, (float)model->S, (float)dt};
+      ModelT<float> m = {(float)(model->nMax - p->base_n), (float)model->D, (float)model->r, (float)model->alpha,
+                         (float)model->S, (float)dt, (float)p->base_n, (float)(1.0 / (1.0 + p->base_n))};
       hipLaunchKernelGGL(sell_step_kernel<float>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
                          p->V, p->nslices, p->nblocks, m);
     } else {
-      ModelT<double> m = {model->nMax, model->D, model->r, model->alpha, model->S, dt};
+      ModelT<double> m = {model->nMax - p->base_n, model->D, model->r, model->alpha, model->S, dt, p->base_n,
+                          1.0 / (1.0 + p->base_n)};
       hipLaunchKernelGGL(sell_step_kernel<double>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const double2 *)src, (double2 *)dst, p->slice_off.p, p->idx.p, (const double4 *)p->coef,
                          p->V, p->nslices, p->nblocks, m);
@@ -464,8 +477,11 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
   return FEM_OK;
 }
 
-int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, int *scalar_bytes) {
+int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, int *scalar_bytes,
+                   double *base_n, double *base_c) {
   if (!p) return fail(FEM_ERR_INVALID, "fem_plan_state: null");
+  if (base_n) *base_n = p->base_n;
+  if (base_c) *base_c = p->base_c;
   if (dev_ptr) *dev_ptr = (uint64_t)p->state[p->cur];
   if (n_vertices) *n_vertices = p->V;
   if (scalar_bytes) *scalar_bytes = p->precision == FEM_PREC_F32 ? 4 : 8;

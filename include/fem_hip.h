@@ -201,18 +201,25 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
  * precision = FEM_PREC_F32 or FEM_PREC_F64.  Vertices [own_begin, own_end)
  * are advanced by this plan; the others are ghosts whose state the caller
  * refreshes between steps (multi-GPU shards).  own_begin=0, own_end=V for a
- * whole mesh. */
+ * whole mesh.
+ * State representation: the device buffers hold DEVIATIONS from the homogeneous
+ * state (base_n, base_c) = (nMax, nMax/(1+nMax)) of the model given at creation
+ * (NULL = fem_default_model), so that fp32 storage does not round at the
+ * magnitude of n itself; set/get_state convert in double.  fem_plan_run may be
+ * given different constants later; the rewrite stays exact for any of them. */
 typedef struct fem_plan fem_plan;
-int fem_plan_create(const fem_mesh *ordered, int precision, fem_plan **out);
+int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out);
 void fem_plan_destroy(fem_plan *p);
 int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn);
 int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn);
 /* nsteps explicit Euler steps, ping-ponging the plan's two buffers; async on
  * `stream`.  One call = the reference's timed loop body (main.cpp:558-562). */
 int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream);
-/* device pointer of the current state buffer (interleaved (n,c) pairs of the
- * plan's scalar type), its element count, and bytes per scalar */
-int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, int *scalar_bytes);
+/* device pointer of the current state buffer (interleaved (n - base_n,
+ * c - base_c) pairs of the plan's scalar type), its vertex count, bytes per
+ * scalar and the two base values */
+int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, int *scalar_bytes,
+                   double *base_n, double *base_c);
 /* operator footprint in device memory (bytes read per step, excluding state) */
 uint64_t fem_plan_operator_bytes(const fem_plan *p);
 

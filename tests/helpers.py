@@ -1,0 +1,54 @@
+"""shared builders for the tests (inputs only; nothing here is under test)"""
+import numpy as np
+
+import fem_amd as fa
+import oracle_lib as ol
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def smooth_ic(pts, nMax=1.0, amp=0.005):
+    """smooth initial condition (low spherical/planar harmonics), |beta| <= amp, c = 1/(1+n)
+    as at reference src/main.cpp:182-186"""
+    p = pts / max(np.abs(pts).max(), 1e-300)
+    beta = amp * (0.5 * np.sin(3.0 * p[:, 0] + 0.3) * np.cos(2.0 * p[:, 1]) + 0.5 * np.sin(2.5 * p[:, 2] + 1.0))
+    n = nMax - beta
+    return n, 1.0 / (1.0 + n)
+
+
+class Case:
+    """a mesh, partitioned and reordered by the product, with the oracle's tables of the ORDERED mesh"""
+
+    def __init__(self, pts, tri, nparts, seed=1):
+        self.orig = fa.Mesh(pts, tri)
+        self.part = self.orig.partition(nparts)
+        self.mesh = self.part.ordered
+        self.pts, self.tri = self.mesh.points, self.mesh.tri
+        self.V, self.F, self.n = self.mesh.V, self.mesh.F, nparts
+        self.topo = ol.Topology(self.V, self.tri)
+        self._stats = {}
+        self.model = fa.default_model()
+        self.n0, self.c0 = ol.initial_condition(self.V, seed)
+
+    def ostats(self, prec):
+        if prec not in self._stats:
+            self._stats[prec] = ol.Stats(self.topo, self.pts, prec)
+        return self._stats[prec]
+
+    @property
+    def dt(self):
+        # dt = 0.1 * maxEdgeLen^2, reference src/main.cpp:188
+        return 0.1 * self.ostats(ol.MIXED).maxEdgeLen ** 2
+
+
+def sphere_case(nu=8, nparts=4, **kw):
+    pts, tri = fa.make_icosphere(nu, 0.1)
+    return Case(pts, tri, nparts, **kw)
+
+
+def strip_case(nparts=3, **kw):
+    pts, tri = fa.make_strip(11, 41, 0.1)
+    return Case(pts, tri, nparts, **kw)

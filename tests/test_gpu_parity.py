@@ -1,0 +1,195 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+
+Bars:
+  * `step` / fem_step on the reference layout (fp64 state, fp32 gradient branch, LDS float
+    atomics as in the reference): rel-L2 <= 1e-8 against the oracle's mixed-precision CPUrun.
+    Not bit-exact by construction: the reference's own float-atomic scatter is order-dependent
+    (error per step ~ alpha*dt*|Gn.Gc|*2^-24, about 1e-10 absolute on these inputs).
+  * native plan, fp64: rel-L2 <= 1e-11 against the all-fp64 oracle (same arithmetic, folded).
+  * native plan, fp32: rel-L2 <= 1e-5 against the all-fp64 oracle after 100 steps from a
+    smooth initial condition (the tolerance BASELINE.json's north_star states).
+"""
+import numpy as np
+import pytest
+
+import fem_amd as fa
+import oracle_lib as ol
+from helpers import rel_l2, smooth_ic, sphere_case, strip_case
+
+pytestmark = pytest.mark.gpu
+
+TOL_REF = 1e-8
+TOL_F64 = 1e-11
+TOL_F32 = 1e-5
+
+
+def _ref_device(case):
+    case.mesh.init_stats(fa.PREC_MIXED)
+    lay = fa.RefLayout(case.part)
+    return lay, fa.RefDevice(lay)
+
+
+@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(8, n), 4), (lambda n: strip_case(n), 3),
+                                         (lambda n: sphere_case(32, n), 52)])
+def test_reference_step_symbol(make, nparts):
+    """the reference's own 21-argument `step`, ping-ponged as at main.cpp:481-483"""
+    case = make(nparts)
+    lay, dev = _ref_device(case)
+    dev.set_state(case.n0, case.c0)
+    a = dev.args()
+    fa.step(a, "fn_one", "fn_two", case.dt)
+    fa.step(a, "fn_two", "fn_one", case.dt)
+    n_gpu, c_gpu = dev.get_state()          # fn_one is current again
+    n_ref, c_ref = case.ostats(ol.MIXED).step(case.n0, case.c0, case.dt, 2, case.model.as_array())
+    assert rel_l2(n_gpu, n_ref) <= TOL_REF and rel_l2(c_gpu, c_ref) <= TOL_REF
+    assert not np.array_equal(n_gpu, case.n0)
+
+
+def test_reference_layout_run_vs_packed_oracle():
+    """fem_ref_device_run (20 steps) against the literal CPU model of stepKernel on the oracle's
+    own packed arrays"""
+    case = sphere_case(8, 5)
+    lay, dev = _ref_device(case)
+    dev.set_state(case.n0, case.c0)
+    dev.run(20, case.dt, case.model)
+    n_gpu, c_gpu = dev.get_state()
+    olay = ol.pack_ref_layout(case.ostats(ol.MIXED), case.n, case.part.node_parts, case.part.element_parts)
+    fn = np.stack([case.n0, case.c0], axis=1)
+    for _ in range(20):
+        fn = ol.step_packed(olay, case.n, case.part.node_parts, case.model.as_array(), case.dt, fn)
+    assert rel_l2(n_gpu, fn[:, 0]) <= TOL_REF and rel_l2(c_gpu, fn[:, 1]) <= TOL_REF
+
+
+def test_reference_step_custom_model_and_clamp():
+    """alt constant set of main.cpp:49-54 and the max(0, .) clamp (FEM_common.cu:164-165).
+    Rough state + large dt: the fp32 gradient branch dominates the error, hence the looser bar."""
+    case = strip_case(4)
+    lay, dev = _ref_device(case)
+    model = fa.default_model()
+    model.r, model.alpha = 1.52, 12.02
+    n0 = case.n0.copy()
+    c0 = case.c0.copy()
+    n0[::7] = 0.0                       # neighbours of these are driven negative -> clamped to 0
+    dev.set_state(n0, c0)
+    dev.run(2, 20 * case.dt, model)
+    n_gpu, c_gpu = dev.get_state()
+    n_ref, c_ref = case.ostats(ol.MIXED).step(n0, c0, 20 * case.dt, 2, model.as_array())
+    assert (n_ref == 0).sum() > 10
+    assert (n_gpu >= 0).all() and (c_gpu >= 0).all()
+    assert np.abs(n_gpu[n_ref == 0]).max() <= 1e-5 and np.abs(n_ref[n_gpu == 0]).max() <= 1e-5
+    assert rel_l2(n_gpu, n_ref) <= 1e-6 and rel_l2(c_gpu, c_ref) <= 1e-6
+
+
+def test_reference_step_limits_and_errors():
+    case = sphere_case(4, 1)            # one partition, 162 vertices, 320 faces
+    lay, dev = _ref_device(case)
+    a = dev.args()
+    # aliased src/dst is rejected, nothing launched, error retrievable as the void shim requires
+    fa.lib.step(a["fn_one"], a["fn_one"], a["fv"], a["fv_weights"], a["fv_pitch"], a["fvw_pitch"], a["nbr"],
+                a["vtxW"], a["vw_pitch"], a["vertex_weights"], a["vv_pitch"], a["vws_pitch"], a["vv_size"],
+                a["grads"], a["he_pitch"], a["parts_n"], a["block_face_count"], a["blocks"], a["threads"], 0.001,
+                a["smem_size"])
+    assert fa.lib.fem_last_error() == -1
+    # > 1024 vertices per partition: refused like GPUrun does (main.cpp:357-360)
+    big = sphere_case(12, 1)
+    big.mesh.init_stats(fa.PREC_MIXED)
+    with pytest.raises(fa.FemError):
+        fa.RefDevice(fa.RefLayout(big.part))
+
+
+@pytest.mark.parametrize("make,nparts,steps", [(lambda n: sphere_case(8, n), 4, 10), (lambda n: strip_case(n), 3, 10),
+                                               (lambda n: sphere_case(32, n), 52, 100)])
+def test_native_plan_f64(make, nparts, steps):
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_F64)
+    plan = fa.Plan(case.mesh, fa.PREC_F64)
+    plan.set_state(case.n0, case.c0)
+    plan.run(steps, case.dt, case.model)
+    n_gpu, c_gpu = plan.get_state()
+    n_ref, c_ref = case.ostats(ol.F64).step(case.n0, case.c0, case.dt, steps, case.model.as_array())
+    assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+
+
+@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(32, n), 52), (lambda n: strip_case(n), 3)])
+def test_native_plan_f32_100_steps(make, nparts):
+    """BASELINE config 1 shape: V = 10 242 sphere (P = 52) and the 451-vertex strip, 100 steps"""
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_F64)
+    n0, c0 = smooth_ic(case.pts)
+    plan = fa.Plan(case.mesh, fa.PREC_F32)
+    plan.set_state(n0, c0)
+    plan.run(100, case.dt, case.model)
+    n_gpu, c_gpu = plan.get_state()
+    # the fp32 path starts from the fp32-rounded state; give the oracle the same start
+    n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+    n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
+    assert rel_l2(n_gpu, n_ref) <= TOL_F32 and rel_l2(c_gpu, c_ref) <= TOL_F32
+
+
+def test_native_plan_f32_random_ic_and_mixed_oracle():
+    """random (rough) IC of main.cpp:182-186, 100 steps; also within tolerance of the reference's
+    own precision mix"""
+    case = sphere_case(32, 52, seed=7)
+    case.mesh.init_stats(fa.PREC_F64)
+    plan = fa.Plan(case.mesh, fa.PREC_F32)
+    plan.set_state(case.n0, case.c0)
+    plan.run(100, case.dt, case.model)
+    n_gpu, c_gpu = plan.get_state()
+    n0r, c0r = case.n0.astype(np.float32).astype(np.float64), case.c0.astype(np.float32).astype(np.float64)
+    for prec in (ol.F64, ol.MIXED):
+        n_ref, c_ref = case.ostats(prec).step(n0r, c0r, case.dt, 100, case.model.as_array())
+        assert rel_l2(n_gpu, n_ref) <= TOL_F32 and rel_l2(c_gpu, c_ref) <= TOL_F32
+
+
+def test_native_plan_ragged_sizes():
+    """V not a multiple of 64, a single slice, boundary vertices, valence-5 rows"""
+    for pts_tri, nparts in ((fa.make_icosphere(1, 0.1), 1), (fa.make_icosphere(3, 0.1), 2), (fa.make_strip(2, 2, 0.1), 1),
+                            (fa.make_strip(5, 13, 0.1), 2)):
+        from helpers import Case
+        case = Case(pts_tri[0], pts_tri[1], nparts)
+        case.mesh.init_stats(fa.PREC_F64)
+        plan = fa.Plan(case.mesh, fa.PREC_F64)
+        plan.set_state(case.n0, case.c0)
+        plan.run(5, case.dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        n_ref, c_ref = case.ostats(ol.F64).step(case.n0, case.c0, case.dt, 5, case.model.as_array())
+        assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+
+
+def test_native_plan_full_size_properties():
+    """1M-vertex sphere (BASELINE config 2 size): size-independent properties.
+    (i) a constant state is a fixed point of diffusion/chemotaxis: with r = 0 one step changes
+        n by exactly 0 and c only through S*(n/(1+n) - c) = 0;
+    (ii) determinism: two runs from the same state agree bit for bit (no atomics);
+    (iii) sampled rows of the fp32 result match the fp64 plan within tolerance."""
+    pts, tri = fa.make_icosphere(320, 0.1)
+    mesh = fa.Mesh(pts, tri)
+    part = mesh.partition(4096)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
+    model = fa.default_model()
+    plan = fa.Plan(om, fa.PREC_F32)
+    # (i)
+    m0 = fa.default_model()
+    m0.r = 0.0
+    n_const = np.full(om.V, 0.75)
+    c_const = n_const / (1 + n_const)
+    plan.set_state(n_const, c_const)
+    plan.run(1, dt, m0)
+    n1, c1 = plan.get_state()
+    assert np.array_equal(n1, n_const.astype(np.float32).astype(np.float64))
+    assert np.abs(c1 - c_const).max() <= 1e-7
+    # (ii) + (iii)
+    n0, c0 = smooth_ic(om.points)
+    outs = []
+    for _ in range(2):
+        plan.set_state(n0, c0)
+        plan.run(20, dt, model)
+        outs.append(plan.get_state())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    plan64 = fa.Plan(om, fa.PREC_F64)
+    plan64.set_state(n0.astype(np.float32), c0.astype(np.float32))
+    plan64.run(20, dt, model)
+    n64, c64 = plan64.get_state()
+    assert rel_l2(outs[0][0], n64) <= TOL_F32 and rel_l2(outs[0][1], c64) <= TOL_F32
