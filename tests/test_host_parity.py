@@ -1,0 +1,184 @@
+"""Host side of the product (libfem_hip.so, no GPU needed) against the CPU oracle:
+bit-exact for integer/index work (half-edge tables = CSR sparsity pattern, partition
+renumbering, halo faces, packed index arrays), <= 1e-12 relative for the assembled weights."""
+import os
+
+import numpy as np
+import pytest
+
+import fem_amd as fa
+import oracle_lib as ol
+from helpers import Case
+
+MESHES = {
+    "ico1": lambda: fa.make_icosphere(1, 0.1),
+    "ico9": lambda: fa.make_icosphere(9, 0.1),
+    "strip": lambda: fa.make_strip(11, 41, 0.1),
+    "strip2x2": lambda: fa.make_strip(2, 2, 0.1),
+    "single": lambda: (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0.0]]), np.array([[0, 1, 2]], np.uint32)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MESHES))
+def test_topology_bit_exact(name):
+    pts, tri = MESHES[name]()
+    m = fa.Mesh(pts, tri)
+    t = ol.Topology(m.V, tri)
+    pt = m.topology()
+    assert m.H == t.H
+    for k in ("opp", "he_from", "he_to", "rowptr", "col", "row_he"):
+        assert np.array_equal(pt[k], getattr(t, k)), k
+    # CSR pattern properties: ascending unique columns, symmetric, no self loops
+    for v in range(m.V):
+        cols = pt["col"][pt["rowptr"][v]:pt["rowptr"][v + 1]]
+        assert np.all(np.diff(cols.astype(np.int64)) > 0) and v not in cols
+    assert np.array_equal(pt["he_from"][pt["opp"]], pt["he_to"])
+
+
+@pytest.mark.parametrize("name", ["ico9", "strip", "single"])
+@pytest.mark.parametrize("prec", [(ol.F64, fa.PREC_F64), (ol.MIXED, fa.PREC_MIXED)])
+def test_mesh_stats_match_oracle(name, prec):
+    pts, tri = MESHES[name]()
+    m = fa.Mesh(pts, tri).init_stats(prec[1])
+    so = ol.Stats(ol.Topology(m.V, tri), pts, prec[0])
+    sp = m.stats()
+    for k in ("meshAngle", "meshCot", "meshArea", "areaPerVtx", "wHej", "wVtx", "gradVec12", "gradVec13"):
+        a, b = np.asarray(getattr(so, k), np.float64), sp[k]
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(a).max(), 1e-300), k
+    assert sp["maxEdgeLen"] == so.maxEdgeLen
+    # CPU operators kept by name (mesh_function.h:6-110)
+    f = np.cos(3 * pts[:, 0]) + pts[:, 1] ** 2
+    assert np.allclose(m.laplacian_cpu(f), so.laplacian(f), rtol=0, atol=1e-12 * np.abs(so.wVtx).max())
+    fg = m.face_gradients_cpu(f)
+    assert np.allclose(fg, so.face_gradients(f), rtol=0, atol=1e-12 * np.abs(fg).max())
+    vg = m.vertex_gradients_cpu(fg)
+    assert np.allclose(vg, so.vertex_gradients(so.face_gradients(f)), rtol=0, atol=1e-6 * np.abs(vg).max())
+
+
+def test_mesh_errors():
+    pts, tri = MESHES["ico1"]()
+    bad = tri.copy()
+    bad[0] = bad[0][::-1]                      # flipped face: a directed edge now occurs twice
+    with pytest.raises(fa.FemError, match="manifold"):
+        fa.Mesh(pts, bad)
+    with pytest.raises(ValueError):
+        ol.Topology(len(pts), bad)
+    bad = tri.copy()
+    bad[3, 1] = 99                             # index out of range
+    with pytest.raises(fa.FemError):
+        fa.Mesh(pts, bad)
+    with pytest.raises(fa.FemError):
+        fa.Mesh(pts, tri).stats()              # stats not initialised
+
+
+@pytest.mark.parametrize("name,n", [("ico9", 7), ("strip", 3), ("ico1", 1), ("ico1", 12)])
+def test_partition_contract_bit_exact(name, n):
+    """R1-R3 of partitioning_common.cpp:78-176 on the product's own vertex parts"""
+    pts, tri = MESHES[name]()
+    m = fa.Mesh(pts, tri)
+    npart = m.partition_vertices(n)
+    assert npart.min() == 0 and npart.max() == n - 1
+    sizes = np.bincount(npart, minlength=n)
+    assert sizes.max() - sizes.min() <= 1                      # balanced split
+    part = m.partition(n)
+    pv, pf, nparts, eparts, pts_o, tri_o = ol.partition_apply(m.V, pts, tri, npart, n)
+    assert np.array_equal(part.perm_v, pv) and np.array_equal(part.perm_f, pf)
+    assert np.array_equal(part.node_parts, nparts) and np.array_equal(part.element_parts, eparts)
+    assert np.array_equal(part.ordered.points, pts_o) and np.array_equal(part.ordered.tri, tri_o)
+    # contract properties: permutations; vertices of part p are [node_parts[p], node_parts[p+1]);
+    # faces in bucket p < n lie wholly inside part p, the last bucket holds the cut faces
+    assert np.array_equal(np.sort(part.perm_v), np.arange(m.V))
+    assert np.array_equal(np.sort(part.perm_f), np.arange(m.F))
+    owner = np.searchsorted(part.node_parts, tri_o, side="right") - 1
+    for p in range(n):
+        fp = owner[part.element_parts[p]:part.element_parts[p + 1]]
+        assert np.all(fp == p)
+    cutf = owner[part.element_parts[n]:part.element_parts[n + 1]]
+    assert np.all(cutf.min(axis=1) != cutf.max(axis=1)) if len(cutf) else True
+    # an arbitrary (non-geometric) npart goes through the same contract
+    rng = np.random.default_rng(1)
+    rnd = rng.integers(0, n, m.V)
+    rnd[:n] = np.arange(n)
+    part2 = m.partition(n, npart=rnd)
+    pv, pf, nparts, eparts, pts_o, tri_o = ol.partition_apply(m.V, pts, tri, rnd, n)
+    assert np.array_equal(part2.perm_v, pv) and np.array_equal(part2.perm_f, pf)
+    assert np.array_equal(part2.ordered.tri, tri_o) and np.array_equal(part2.element_parts, eparts)
+
+
+def test_partition_golden_fixture():
+    """regression pin of the Hilbert split (the stage METIS occupied): committed vertex parts of
+    the nu=9 sphere (n=7) and the strip (n=3); generator: tests/golden/make_golden.py"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "partition_golden.npz"))
+    for name, n in (("ico9", 7), ("strip", 3)):
+        pts, tri = MESHES[name]()
+        assert np.array_equal(fa.Mesh(pts, tri).partition_vertices(n), g["%s_n%d" % (name, n)])
+
+
+@pytest.mark.parametrize("name,n", [("ico9", 7), ("strip", 3), ("ico1", 1)])
+def test_reference_layout_bit_exact(name, n):
+    """initializeGPUData (main.cpp:207-342): halo faces and every padded array"""
+    pts, tri = MESHES[name]()
+    case = Case(pts, tri, n)
+    case.mesh.init_stats(fa.PREC_MIXED)
+    lay = fa.RefLayout(case.part)
+    mine = lay.arrays()
+    ref = ol.pack_ref_layout(case.ostats(ol.MIXED), n, case.part.node_parts, case.part.element_parts)
+    assert (lay.maxV, lay.W, lay.maxF) == (ref["maxV"], ref["W"], ref["maxF"])
+    for k in mine:
+        if mine[k].size == 0:
+            assert ref[k].size == 0, k
+        elif mine[k].dtype.kind in "ui":
+            assert np.array_equal(mine[k], ref[k]), k
+        else:
+            assert np.abs(mine[k] - ref[k]).max() <= 1e-12 * np.abs(ref[k]).max(), k
+    # every face touching partition p appears exactly once among its interior+halo slots
+    fv = mine["face_vertices"]
+    for p in range(n):
+        cnt = mine["block_face_count"][p]
+        faces = {tuple(fv[p, :, s]) for s in range(cnt)}
+        assert len(faces) == cnt
+        lo, hi = case.part.node_parts[p], case.part.node_parts[p + 1]
+        touching = {tuple(f) for f in case.tri if ((f >= lo) & (f < hi)).any()}
+        assert faces == touching
+
+
+def test_initial_condition_bit_exact():
+    for seed in (0, 1, 12345):
+        a, b = fa.initial_condition(5000, seed), ol.initial_condition(5000, seed)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_off_roundtrip(tmp_path):
+    pts, tri = MESHES["ico9"]()
+    rgb = (np.arange(3 * len(pts)) % 256).astype(np.uint8).reshape(-1, 3)
+    path = str(tmp_path / "m.off")
+    fa.off_write(path, pts, tri, rgb)
+    p2, t2, c2 = fa.off_read(path)
+    assert np.allclose(p2, pts, rtol=1e-8) and np.array_equal(t2, tri) and np.array_equal(c2, rgb)
+    fa.off_write(path, pts, tri)
+    p3, t3, c3 = fa.off_read(path)
+    assert c3 is None and np.array_equal(t3, tri)
+    # quads are fan-triangulated like a TriMesh import; comments and blank lines are skipped
+    with open(path, "w") as f:
+        f.write("# comment\nOFF\n4 1 0\n0 0 0\n1 0 0\n1 1 0\n\n0 1 0\n4 0 1 2 3\n")
+    p4, t4, _ = fa.off_read(path)
+    assert np.array_equal(t4, [[0, 1, 2], [0, 2, 3]])
+    with pytest.raises(fa.FemError):
+        fa.off_read(str(tmp_path / "missing.off"))
+    with open(path, "w") as f:
+        f.write("PLY\n")
+    with pytest.raises(fa.FemError):
+        fa.off_read(path)
+
+
+def test_icosphere_generator():
+    for nu in (1, 2, 3, 10):
+        pts, tri = fa.make_icosphere(nu, 0.1)
+        assert len(pts) == 10 * nu * nu + 2 and len(tri) == 20 * nu * nu
+        deg = np.diff(fa.Mesh(pts, tri).topology()["rowptr"])
+        assert (deg == 5).sum() == 12 and (deg == 6).sum() == len(pts) - 12
+        # outward orientation: positive signed volume
+        vol = np.einsum("ij,ij->i", pts[tri[:, 0]], np.cross(pts[tri[:, 1]], pts[tri[:, 2]])).sum() / 6
+        assert vol > 0
+        e = np.linalg.norm(pts[tri[:, 0]] - pts[tri[:, 1]], axis=1)
+        assert 0.8 < e.mean() / 0.1 < 1.2

@@ -1,0 +1,89 @@
+"""The only output artefact the reference holds: ResultantPattern.off (451 vertices, 800 faces,
+8-bit colours R = round(255 n^), G = B = 255 - R; colour law of src/FEM_common.cu:183-194).
+tests/golden/ResultantPattern.off is a copy of that data file.
+
+Finding (DESIGN.md "Oracle pinning"): the pattern in the file is the unstable eigenmode of the
+model with the constant set of the reference's CPU path (src/main.cpp:49-54: r = 1.52,
+alpha = 12.02), whose critical wavelength 2 pi / sqrt(2.47) = 4.0 is exactly the strip's length;
+with the kernel's set (src/FEM_common.cu:9-13) the homogeneous state is stable on this mesh.
+Running the restated step law from the reference's IC law reproduces the file's colours to
+<= 10/255 per vertex (correlation >= 0.999) -- for the CPU oracle and for the HIP `step`.
+Step count and RNG state of the original run are unknown, so this is a shape check in the
+linear-growth regime, not a bit-level golden."""
+import os
+
+import numpy as np
+import pytest
+
+import fem_amd as fa
+import oracle_lib as ol
+from helpers import Case
+
+PATH = os.path.join(os.path.dirname(__file__), "golden", "ResultantPattern.off")
+STEPS = 60000
+
+
+def colours_of(n):
+    return np.round(255 * (n - n.min()) / (n.max() - n.min()))
+
+
+def alt_model():
+    m = fa.default_model()
+    m.r, m.alpha = 1.52, 12.02
+    return m
+
+
+def test_file_loads_and_matches_strip_generator():
+    pts, tri, rgb = fa.off_read(PATH)
+    assert pts.shape == (451, 3) and tri.shape == (800, 3) and rgb.shape == (451, 3)
+    p2, t2 = fa.make_strip(11, 41, 0.1)
+    assert np.array_equal(tri, t2) and np.abs(pts - p2).max() < 1e-5
+    R = rgb[:, 0].astype(int)
+    assert np.abs(rgb[:, 1].astype(int) - (255 - R)).max() <= 1 and np.array_equal(rgb[:, 1], rgb[:, 2])
+    assert R.min() == 0 and R.max() == 255
+    # quasi 1-D along the 41-vertex axis, about one full period
+    g = R.reshape(11, 41)
+    assert np.abs(g - g.mean(0)).max() <= 2
+    assert np.argmin(g.mean(0)) in (19, 20) and g.mean(0)[0] > 250 and g.mean(0)[-1] > 240
+
+
+def test_oracle_reproduces_the_pattern():
+    pts, tri, rgb = fa.off_read(PATH)
+    R = rgb[:, 0].astype(float)
+    t = ol.Topology(len(pts), tri)
+    s = ol.Stats(t, pts, ol.MIXED)
+    dt = 0.1 * s.maxEdgeLen ** 2                      # main.cpp:188
+    n0, c0 = ol.initial_condition(t.V, 1)
+    n, c = s.step(n0, c0, dt, STEPS, alt_model().as_array())
+    col = colours_of(n)
+    assert np.corrcoef(col, R)[0, 1] >= 0.999 and np.abs(col - R).max() <= 10
+    # the kernel's constant set does not produce it (homogeneous state is stable there)
+    n, c = s.step(n0, c0, dt, STEPS, fa.default_model().as_array())
+    assert abs(np.corrcoef(colours_of(n), R)[0, 1]) < 0.5
+    assert np.ptp(n) < 0.2 * np.ptp(n0)
+
+
+@pytest.mark.gpu
+def test_hip_step_reproduces_the_pattern():
+    """the reference's `step` symbol on the reference layout, 3 partitions, 60 000 launches"""
+    pts, tri, rgb = fa.off_read(PATH)
+    R = rgb[:, 0].astype(float)
+    case = Case(pts, tri, 3)
+    case.mesh.init_stats(fa.PREC_MIXED)
+    dev = fa.RefDevice(fa.RefLayout(case.part))
+    n0, c0 = ol.initial_condition(case.V, 1)          # IC in file order, permuted to the ordered mesh
+    n_ord, c_ord = np.empty_like(n0), np.empty_like(c0)
+    n_ord[case.part.perm_v], c_ord[case.part.perm_v] = n0, c0
+    dev.set_state(n_ord, c_ord)
+    dev.run(STEPS, case.dt, alt_model())
+    n_gpu, _ = dev.get_state()
+    col = colours_of(n_gpu[case.part.perm_v])         # back to file order
+    assert np.corrcoef(col, R)[0, 1] >= 0.999 and np.abs(col - R).max() <= 10
+    # and the native fp32 plan
+    case.mesh.init_stats(fa.PREC_F64)
+    plan = fa.Plan(case.mesh, fa.PREC_F32, alt_model())
+    plan.set_state(n_ord, c_ord)
+    plan.run(STEPS, case.dt, alt_model())
+    n32, _ = plan.get_state()
+    col = colours_of(n32[case.part.perm_v])
+    assert np.corrcoef(col, R)[0, 1] >= 0.999 and np.abs(col - R).max() <= 10
