@@ -15,6 +15,15 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfem_hip.so")
 
 PREC_MIXED, PREC_F64, PREC_F32 = 0, 1, 2
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same soname as
+# /opt/rocm's).  If torch is imported AFTER this library has pulled in /opt/rocm's copy, a second
+# runtime gets loaded and torch sees no GPU.  Importing torch first makes the dynamic loader
+# reuse torch's copy for libfem_hip.so as well.  Without torch the system runtime is used.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 if not os.path.exists(LIB_PATH):
     raise ImportError(
         "fem_amd: %s is missing -- build it first (make -C fem_amd/csrc). "
@@ -47,7 +56,9 @@ lib.fem_error_detail.restype = C.c_char_p
 lib.fem_plan_operator_bytes.restype = C.c_uint64
 lib.fem_plan_operator_bytes.argtypes = [vp]
 lib.fem_free.argtypes = [vp]
-for _name in ("fem_mesh_destroy", "fem_ref_layout_destroy", "fem_ref_device_destroy", "fem_plan_destroy"):
+lib.fem_plan_pack_halo.argtypes = [vp, C.c_uint64, vp]
+for _name in ("fem_mesh_destroy", "fem_ref_layout_destroy", "fem_ref_device_destroy", "fem_plan_destroy",
+              "fem_shard_destroy"):
     getattr(lib, _name).argtypes = [vp]
     getattr(lib, _name).restype = None
 
@@ -317,14 +328,48 @@ def step(a, src, dst, dt):
     _check(lib.fem_last_error())
 
 
+class Shard:
+    """fem_shard: one rank's contiguous partition range of an ordered mesh + k ghost rings."""
+
+    def __init__(self, part, rank, nranks, krings=1):
+        h = vp()
+        _check(lib.fem_shard_create(part.ordered.h, C.c_int(part.n), _ptr(part.node_parts, u32p), C.c_int(rank),
+                                    C.c_int(nranks), C.c_int(krings), C.byref(h)))
+        self.h, self.rank, self.nranks, self.krings = h, rank, nranks, krings
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib.fem_shard_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.own_begin, self.own_end, self.n_local, self.n_send = a.value, b.value, c.value, d.value
+        self.n_own = self.own_end - self.own_begin
+        l2g, sidx, sc, rc = u32p(), u32p(), C.POINTER(C.c_int)(), C.POINTER(C.c_int)()
+        lib.fem_shard_arrays(self.h, C.byref(l2g), C.byref(sidx), C.byref(sc), C.byref(rc))
+        self.loc2glob = np.ctypeslib.as_array(l2g, shape=(self.n_local,)).copy()
+        self.send_idx = (np.ctypeslib.as_array(sidx, shape=(self.n_send,)).copy() if self.n_send
+                         else np.zeros(0, np.uint32))
+        self.send_counts = np.ctypeslib.as_array(sc, shape=(nranks,)).copy()
+        self.recv_counts = np.ctypeslib.as_array(rc, shape=(nranks,)).copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.fem_shard_destroy(self.h)
+            self.h = None
+
+
 class Plan:
     """Native plan: sliced-ELL operator + ping-pong state on the device."""
 
-    def __init__(self, ordered, precision=PREC_F32, model=None):
+    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None):
         h = vp()
         mp = C.byref(model) if model is not None else None
-        _check(lib.fem_plan_create(ordered.h, C.c_int(precision), mp, C.byref(h)))
-        self.h, self.V, self.precision = h, ordered.V, precision
+        if shard is None:
+            _check(lib.fem_plan_create(ordered.h, C.c_int(precision), mp, C.byref(h)))
+            self.V = ordered.V
+        else:
+            _check(lib.fem_plan_create_shard(ordered.h, shard.h, C.c_int(precision), mp, C.byref(h)))
+            self.V = shard.n_local
+        self.h, self.precision = h, precision
+
+    def pack_halo(self, dst_ptr, stream=None):
+        _check(lib.fem_plan_pack_halo(self.h, C.c_uint64(dst_ptr), vp(stream or 0)))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -245,4 +245,34 @@ void fem_ref_layout_arrays(const fem_ref_layout *l, const fem_uint **halo_faces_
   if (he_grads) *he_grads = l->l.he_grads.data();
 }
 
+// ---- shards ---------------------------------------------------------------------------------
+
+int fem_shard_create(const fem_mesh *ordered, int n, const fem_uint *node_parts, int rank, int nranks,
+                     int krings, fem_shard **out) {
+  if (!ordered || !node_parts || !out) return fail(FEM_ERR_INVALID, "fem_shard_create: null");
+  fem_shard *s = new (std::nothrow) fem_shard();
+  if (!s) return fail(FEM_ERR_ALLOC, "out of memory");
+  int rc = fem::buildShard(ordered->mesh, n, node_parts, rank, nranks, krings, s->s);
+  if (rc != FEM_OK) { delete s; return fail(rc, "fem_shard_create: need 1 <= nranks <= n, 0 <= rank < nranks, krings >= 1"); }
+  *out = s;
+  return FEM_OK;
+}
+
+void fem_shard_destroy(fem_shard *s) { delete s; }
+
+void fem_shard_info(const fem_shard *s, fem_uint *own_begin, fem_uint *own_end, fem_uint *n_local, fem_uint *n_send) {
+  if (own_begin) *own_begin = s->s.own_begin;
+  if (own_end) *own_end = s->s.own_end;
+  if (n_local) *n_local = (fem_uint)s->s.loc2glob.size();
+  if (n_send) *n_send = (fem_uint)s->s.send_idx.size();
+}
+
+void fem_shard_arrays(const fem_shard *s, const fem_uint **loc2glob, const fem_uint **send_idx,
+                      const int **send_counts, const int **recv_counts) {
+  if (loc2glob) *loc2glob = s->s.loc2glob.data();
+  if (send_idx) *send_idx = s->s.send_idx.data();
+  if (send_counts) *send_counts = s->s.send_counts.data();
+  if (recv_counts) *recv_counts = s->s.recv_counts.data();
+}
+
 }  // extern "C"

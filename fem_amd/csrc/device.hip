@@ -191,6 +191,14 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
   if (v < V) dst[v] = o;
 }
 
+// halo pack: dst[i] = state[send_idx[i]] (8 or 16 B per lane, coalesced stores)
+template <typename T2>
+__global__ __launch_bounds__(256) void pack_halo_kernel(const T2 *__restrict__ state, const uint *__restrict__ send_idx,
+                                                        T2 *__restrict__ dst, uint n) {
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = state[send_idx[i]];
+}
+
 template <typename T> struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
@@ -225,7 +233,7 @@ struct fem_plan {
   int precision = FEM_PREC_F32;
   fem_uint V = 0, nslices = 0, nblocks = 0;
   size_t entries = 0;
-  DevBuf<fem_uint> slice_off, idx;
+  DevBuf<fem_uint> slice_off, idx, send_idx;
   void *coef = nullptr;            // float4 / double4 [entries]
   void *state[2] = {nullptr, nullptr};   // deviations from (base_n, base_c), interleaved
   int cur = 0;
@@ -382,20 +390,22 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
 
 void fem_plan_destroy(fem_plan *p) {
   if (!p) return;
-  p->slice_off.release(); p->idx.release();
+  p->slice_off.release(); p->idx.release(); p->send_idx.release();
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
   delete p;
 }
 
-int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out) {
+static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int precision, const fem_model *model,
+                      fem_plan **out) {
   if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64))
     return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");
   fem::SellLayout L;
-  int rc = fem::packSellLayout(ordered->mesh, ordered->stats, L);
+  int rc = shard ? fem::packSellLayout(ordered->mesh, ordered->stats, L, shard->loc2glob.data(), (fem::uint)shard->loc2glob.size())
+                 : fem::packSellLayout(ordered->mesh, ordered->stats, L);
   if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh has no topology/stats or is too large");
   fem_plan *p = new fem_plan();
   p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
@@ -408,6 +418,8 @@ int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *mod
   ok(p->idx.alloc(L.idx.size())) && ok(p->idx.upload(L.idx.data())) &&
   ok(hipMalloc(&p->coef, 4 * sb * (p->entries ? p->entries : 1))) &&
   ok(hipMalloc(&p->state[0], 2 * sb * p->V)) && ok(hipMalloc(&p->state[1], 2 * sb * p->V));
+  if (e == hipSuccess && shard)
+    ok(p->send_idx.alloc(shard->send_idx.size())) && (shard->send_idx.empty() || ok(p->send_idx.upload(shard->send_idx.data())));
   if (e == hipSuccess) {
     if (precision == FEM_PREC_F32) {
       std::vector<float> c32(L.coef.begin(), L.coef.end());
@@ -420,6 +432,31 @@ int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *mod
   }
   if (e != hipSuccess) { fem_plan_destroy(p); return fail(FEM_ERR_DEVICE, "fem_plan_create", e); }
   *out = p;
+  return FEM_OK;
+}
+
+int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out) {
+  return planCreate(ordered, nullptr, precision, model, out);
+}
+
+int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int precision, const fem_model *model,
+                          fem_plan **out) {
+  if (!shard) return fail(FEM_ERR_INVALID, "fem_plan_create_shard: null shard");
+  return planCreate(ordered, &shard->s, precision, model, out);
+}
+
+int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream) {
+  if (!p) return fail(FEM_ERR_INVALID, "fem_plan_pack_halo: null");
+  const fem_uint n = (fem_uint)p->send_idx.n;
+  if (n == 0) return FEM_OK;
+  if (!dst_dev) return fail(FEM_ERR_INVALID, "fem_plan_pack_halo: null destination");
+  if (p->precision == FEM_PREC_F32)
+    hipLaunchKernelGGL(pack_halo_kernel<float2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const float2 *)p->state[p->cur], p->send_idx.p, (float2 *)dst_dev, n);
+  else
+    hipLaunchKernelGGL(pack_halo_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const double2 *)p->state[p->cur], p->send_idx.p, (double2 *)dst_dev, n);
+  HIP_TRY(hipGetLastError());
   return FEM_OK;
 }
 

@@ -120,7 +120,20 @@ struct SellLayout {
   std::vector<uint> idx;                     // [entries]
   std::vector<double> coef;                  // [4*entries] (w, Cx, Cy, Cz)
 };
-int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &out);
+int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &out,
+                   const uint *loc2glob = nullptr, uint nloc = 0);
+
+// One rank's share of an ordered mesh: a contiguous range of partitions (hence of vertices),
+// plus the ghost vertices within `krings` edges of it, and who sends what to whom.
+struct Shard {
+  int rank = 0, nranks = 1, krings = 1;
+  uint own_begin = 0, own_end = 0;           // global (ordered) vertex range owned by this rank
+  std::vector<uint> loc2glob;                // owned (ascending) then ghosts (ascending global id)
+  std::vector<uint> send_idx;                // local ids to send, grouped by destination rank
+  std::vector<int> send_counts, recv_counts; // [nranks]
+};
+int buildShard(const SimpleTriMesh &m, int n, const uint *node_parts, int rank, int nranks, int krings,
+               Shard &out);
 
 // records status + message for fem_last_error()/fem_error_detail(); returns status
 int fail(int status, const char *what);
@@ -134,4 +147,7 @@ struct fem_mesh {
 };
 struct fem_ref_layout {
   fem::RefLayout l;
+};
+struct fem_shard {
+  fem::Shard s;
 };

@@ -95,17 +95,32 @@ int packRefLayout(const SimpleTriMesh &m, const MeshStats &s, int n, const uint 
 // mesh_function.cpp:263-265) and its angle-weighted mean of face gradients
 // (mesh_function.h:35-110) because the hat gradients of a face sum to zero.
 // Rows are padded to the slice width with (idx = own row, coef = 0).
-int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o) {
-  const uint V = m.n_vertices();
+// With a row list (loc2glob[nloc], a shard's owned vertices followed by its ghosts) row r holds
+// the operator row of global vertex loc2glob[r] with column ids remapped to local ones;
+// neighbours outside the list are dropped (only the outermost ghost ring has any, and its rows
+// are never consumed: DESIGN.md "Multi-GPU").
+int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o, const uint *loc2glob, uint nloc) {
+  const uint Vg = m.n_vertices();
   const int H3 = 3 * (int)m.n_faces();
-  if (m.H == 0 || s.precision < 0 || V == 0) return FEM_ERR_INVALID;
+  if (m.H == 0 || s.precision < 0 || Vg == 0) return FEM_ERR_INVALID;
+  const uint V = loc2glob ? nloc : Vg;
+  if (V == 0) return FEM_ERR_INVALID;
+  std::vector<int32_t> glob2loc;
+  if (loc2glob) {
+    glob2loc.assign(Vg, -1);
+    for (uint r = 0; r < nloc; r++) {
+      if (loc2glob[r] >= Vg || glob2loc[loc2glob[r]] >= 0) return FEM_ERR_INVALID;
+      glob2loc[loc2glob[r]] = (int32_t)r;
+    }
+  }
+  auto G = [&](uint r) { return loc2glob ? loc2glob[r] : r; };
   o = SellLayout();
   o.V = V;
   o.nslices = (V + 63) / 64;
   o.slice_off.assign(o.nslices + 1, 0);
   for (uint sl = 0; sl < o.nslices; sl++) {
     uint w = 0;
-    for (uint v = sl * 64; v < std::min(V, sl * 64 + 64); v++) w = std::max(w, (uint)(m.rowptr[v + 1] - m.rowptr[v]));
+    for (uint v = sl * 64; v < std::min(V, sl * 64 + 64); v++) w = std::max(w, (uint)(m.rowptr[G(v) + 1] - m.rowptr[G(v)]));
     uint64_t next = (uint64_t)o.slice_off[sl] + (uint64_t)w * 64;
     if (next > 0xffffffffull) return FEM_ERR_LIMIT;
     o.slice_off[sl + 1] = (uint)next;
@@ -124,10 +139,11 @@ int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o) {
   for (uint sl = 0; sl < o.nslices; sl++) {
     const uint off = o.slice_off[sl], width = (o.slice_off[sl + 1] - off) / 64;
     for (uint lane = 0; lane < 64; lane++) {
-      const uint v = sl * 64 + lane;
-      const uint self = v < V ? v : V - 1;
+      const uint row = sl * 64 + lane;
+      const uint self = row < V ? row : V - 1;
       for (uint k = 0; k < width; k++) o.idx[off + (size_t)k * 64 + lane] = self;
-      if (v >= V) continue;
+      if (row >= V) continue;
+      const uint v = G(row);
       double theta = 0;
       for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
         const int h = m.row_he[e];
@@ -151,7 +167,13 @@ int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o) {
           for (int d = 0; d < 3; d++) C[d] /= theta;
         }
         const size_t pos = off + (size_t)k * 64 + lane;
-        o.idx[pos] = m.col[e];
+        if (loc2glob) {
+          const int32_t lc = glob2loc[m.col[e]];
+          if (lc < 0) continue;                    // neighbour outside the shard: entry stays (self, 0)
+          o.idx[pos] = (uint)lc;
+        } else {
+          o.idx[pos] = m.col[e];
+        }
         o.coef[4 * pos] = s.wHej[h];
         o.coef[4 * pos + 1] = C[0]; o.coef[4 * pos + 2] = C[1]; o.coef[4 * pos + 3] = C[2];
       }

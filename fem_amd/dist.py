@@ -42,3 +42,105 @@ class SingleRun:
         with open(path) as f:
             rec = json.load(f)
         return rec.get("%s:%s:%d" % (self.kernel_name, self.precision, self.V))
+
+
+class _DevView:
+    """zero-copy view of device memory owned by the library, for torch.as_tensor"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+class HipShardStepper:
+    """one rank's sharded plan on its GPU"""
+
+    def __init__(self, ordered, shard, precision, model, n_loc, c_loc):
+        import torch
+        self.torch = torch
+        self.shard = shard
+        self.plan = fa.Plan(ordered, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, model, shard=shard)
+        self.plan.set_state(n_loc, c_loc)
+        self.dtype = torch.float32 if precision == "f32" else torch.float64
+        self.typestr = "<f4" if precision == "f32" else "<f8"
+        self.sendbuf = torch.empty((max(shard.n_send, 1), 2), dtype=self.dtype, device="cuda")
+        self._views = {}
+
+    def step(self, nsteps, dt, model, stream):
+        self.plan.run(nsteps, dt, model, stream.cuda_stream if stream is not None else None)
+
+    def pack(self, stream):
+        self.plan.pack_halo(self.sendbuf.data_ptr(), stream.cuda_stream if stream is not None else None)
+        return self.sendbuf[:self.shard.n_send]
+
+    def ghost_view(self):
+        """tensor aliasing the ghost segment of the plan's CURRENT state buffer"""
+        ptr = self.plan.state_ptr()[0]
+        if ptr not in self._views:
+            full = self.torch.as_tensor(_DevView(ptr, (self.shard.n_local, 2), self.typestr), device="cuda")
+            self._views[ptr] = full[self.shard.n_own:]
+        return self._views[ptr]
+
+    def get_owned(self):
+        n, c = self.plan.get_state()
+        return n[:self.shard.n_own], c[:self.shard.n_own]
+
+
+def exchange_halo(stepper, shard, stream=None, group=None):
+    """one all-to-all-v of boundary state: each rank's send vertices -> the ghost segments of its
+    neighbours' current state buffers.  RCCL (backend nccl) moves device memory directly; with
+    gloo (CPU tests, or several ranks sharing one GPU) the buffers are staged through the host."""
+    import torch
+    import torch.distributed as dist
+    send = stepper.pack(stream)
+    recv = stepper.ghost_view()
+    in_splits, out_splits = [int(x) for x in shard.send_counts], [int(x) for x in shard.recv_counts]
+    if dist.get_backend(group) == "gloo" and send.is_cuda:
+        torch.cuda.synchronize()
+        send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(recv_h, send_h, out_splits, in_splits, group=group)
+        recv.copy_(recv_h)
+    else:
+        dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group)
+
+
+class ShardedRun:
+    """the mesh split along the partition ranges over `world` ranks; k ghost rings let every rank
+    take k steps between two halo exchanges (communication-avoiding explicit stepping)"""
+    kernel_name = "sell_step_kernel"
+
+    def __init__(self, mesh, nparts, rank, world, precision="f32", seed=1, krings=None, make_stepper=None):
+        self.part = mesh.partition(nparts)
+        om = self.part.ordered
+        om.init_stats(fa.PREC_F64)
+        self.dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
+        self.model = fa.default_model()
+        self.precision = precision
+        self.krings = krings or int(os.environ.get("FEM_HALO_RINGS", "8"))
+        self.shard = fa.Shard(self.part, rank, world, self.krings)
+        n0, c0 = fa.initial_condition(om.V, seed)                 # ordered numbering, identical on all ranks
+        l2g = self.shard.loc2glob
+        make_stepper = make_stepper or HipShardStepper
+        self.stepper = make_stepper(om, self.shard, precision, self.model, n0[l2g], c0[l2g])
+        self.V = om.V
+        self.budget = self.krings                                  # ghosts are fresh: k steps allowed
+        self.vertices_per_launch = self.shard.n_local
+        sb = 4 if precision == "f32" else 8
+        plan = getattr(self.stepper, "plan", None)
+        self.layout_bytes_per_launch = (plan.operator_bytes() + 4 * sb * self.shard.n_local) if plan else None
+
+    def run(self, nsteps, stream=None):
+        done = 0
+        while done < nsteps:
+            if self.budget == 0:
+                exchange_halo(self.stepper, self.shard, stream)
+                self.budget = self.krings
+            chunk = min(self.budget, nsteps - done)
+            self.stepper.step(chunk, self.dt, self.model, stream)
+            self.budget -= chunk
+            done += chunk
+
+    def get_owned(self):
+        return self.stepper.get_owned()
+
+    def measured_traffic(self):
+        return None

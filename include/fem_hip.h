@@ -198,10 +198,7 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
  * layout (sliced ELL, 64-row slices, folded gradient coefficients)
  * plus two ping-pong state buffers.  Replaces initializeGPUData + GPUrun's
  * allocations for callers that do not need the reference's array shapes.
- * precision = FEM_PREC_F32 or FEM_PREC_F64.  Vertices [own_begin, own_end)
- * are advanced by this plan; the others are ghosts whose state the caller
- * refreshes between steps (multi-GPU shards).  own_begin=0, own_end=V for a
- * whole mesh.
+ * precision = FEM_PREC_F32 or FEM_PREC_F64.
  * State representation: the device buffers hold DEVIATIONS from the homogeneous
  * state (base_n, base_c) = (nMax, nMax/(1+nMax)) of the model given at creation
  * (NULL = fem_default_model), so that fp32 storage does not round at the
@@ -222,6 +219,34 @@ int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, i
                    double *base_n, double *base_c);
 /* operator footprint in device memory (bytes read per step, excluding state) */
 uint64_t fem_plan_operator_bytes(const fem_plan *p);
+
+/* ------------------------------------------------------------------ */
+/* 5. Sharding over the GPUs of one node (no counterpart in the         */
+/*    reference, which is single-GPU).                    */
+/* ------------------------------------------------------------------ */
+
+/* Rank `rank` of `nranks` owns the contiguous partition range
+ * [rank n / nranks, (rank+1) n / nranks) of an ordered mesh -- a contiguous
+ * vertex range, as partitioning_common.cpp:132-136 lays partitions out -- plus
+ * ghost copies of all vertices within `krings` edges of it.  Local numbering:
+ * owned vertices (ascending), then ghosts (ascending global id, hence grouped
+ * by owner rank).  With k rings a rank takes k steps between halo exchanges. */
+typedef struct fem_shard fem_shard;
+int fem_shard_create(const fem_mesh *ordered, int n, const fem_uint *node_parts, int rank,
+                     int nranks, int krings, fem_shard **out);
+void fem_shard_destroy(fem_shard *s);
+void fem_shard_info(const fem_shard *s, fem_uint *own_begin, fem_uint *own_end, fem_uint *n_local,
+                    fem_uint *n_send);
+/* loc2glob[n_local]; send_idx[n_send] = local ids whose state goes out, grouped by
+ * destination rank; send_counts/recv_counts[nranks] (all-to-all split sizes, in vertices) */
+void fem_shard_arrays(const fem_shard *s, const fem_uint **loc2glob, const fem_uint **send_idx,
+                      const int **send_counts, const int **recv_counts);
+/* Plan over a shard's local vertices; state arrays are n_local long, ghosts included. */
+int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int precision,
+                          const fem_model *model, fem_plan **out);
+/* Gathers the current state of the shard's send vertices into dst_dev (n_send interleaved
+ * pairs of the plan's scalar type, device memory), async on `stream`. */
+int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,134 @@
+"""Multi-GPU path: partition-range shards, k ghost rings, halo exchange.
+CPU (gloo, world_size 2 and 3): the exchange plan + torch.distributed call pattern with the oracle as
+the stepper (NaN-poisoned, so any missing/stale ghost is caught).  GPU: the HIP stepper, several
+shards on one card -- in one process with a loop-back exchange, and as 2 gloo ranks."""
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import fem_amd as fa
+import oracle_lib as ol
+from helpers import rel_l2
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def reference_run(nu, nparts, steps, seed=3):
+    pts, tri = fa.make_icosphere(nu, 0.1)
+    part = fa.Mesh(pts, tri).partition(nparts)
+    om = part.ordered
+    st = ol.Stats(ol.Topology(om.V, om.tri), om.points, ol.F64)
+    dt = 0.1 * st.maxEdgeLen ** 2
+    n0, c0 = fa.initial_condition(om.V, seed)
+    return part, st.step(n0, c0, dt, steps, fa.default_model().as_array())
+
+
+def launch(world, tmp_path, **kw):
+    out = str(tmp_path / "shard")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
+           os.path.join(ROOT, "tests", "dist_worker.py"), "--out", out]
+    for k, v in kw.items():
+        cmd += ["--" + k, str(v)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    subprocess.run(cmd, check=True, timeout=600, env=env, capture_output=True)
+    files = sorted(glob.glob(out + ".*.npz"))
+    assert len(files) == world
+    return [np.load(f) for f in files]
+
+
+@pytest.mark.parametrize("world,krings,steps", [(2, 1, 5), (2, 3, 7), (3, 2, 9)])
+def test_gloo_oracle_stepper(world, krings, steps, tmp_path):
+    nu, nparts = 8, 6
+    part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
+    res = launch(world, tmp_path, backend="oracle", sphere=nu, nparts=nparts, krings=krings, steps=steps)
+    covered = 0
+    for r in res:
+        b, e = int(r["own_begin"]), int(r["own_end"])
+        assert not np.isnan(r["n"]).any() and not np.isnan(r["c"]).any()
+        assert rel_l2(r["n"], n_ref[b:e]) <= 1e-13 and rel_l2(r["c"], c_ref[b:e]) <= 1e-13
+        covered += e - b
+    assert covered == part.ordered.V
+
+
+def test_shard_lists_are_consistent():
+    pts, tri = fa.make_icosphere(12, 0.1)
+    part = fa.Mesh(pts, tri).partition(10)
+    rowptr, col = part.ordered.topology()["rowptr"], part.ordered.topology()["col"]
+    for world, k in ((1, 2), (2, 1), (5, 3)):
+        sh = [fa.Shard(part, r, world, k) for r in range(world)]
+        assert sum(s.n_own for s in sh) == part.ordered.V
+        for s in sh:
+            assert np.array_equal(s.loc2glob[:s.n_own], np.arange(s.own_begin, s.own_end))
+            g = s.loc2glob[s.n_own:]
+            assert np.all(np.diff(g.astype(np.int64)) > 0) and not ((g >= s.own_begin) & (g < s.own_end)).any()
+            # ghosts = exactly the vertices within k edges of the owned range (BFS in numpy)
+            dist_ = np.full(part.ordered.V, -1)
+            dist_[s.own_begin:s.own_end] = 0
+            frontier = np.arange(s.own_begin, s.own_end)
+            for ring in range(1, k + 1):
+                nb = np.unique(np.concatenate([col[rowptr[v]:rowptr[v + 1]] for v in frontier])) if len(frontier) else frontier
+                frontier = nb[dist_[nb] < 0]
+                dist_[frontier] = ring
+            assert np.array_equal(g, np.nonzero(dist_ > 0)[0])
+            off = 0
+            for q in range(world):
+                ids = s.loc2glob[s.send_idx[off:off + s.send_counts[q]]]
+                off += s.send_counts[q]
+                gq = sh[q].loc2glob[sh[q].n_own:]
+                assert np.array_equal(ids, gq[(gq >= s.own_begin) & (gq < s.own_end)])
+                assert s.send_counts[q] == sh[q].recv_counts[s.rank]
+    with pytest.raises(fa.FemError):
+        fa.Shard(part, 0, 11, 1)               # more ranks than partitions
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,krings,precision", [(4, 1, "f64"), (4, 3, "f64"), (3, 8, "f32")])
+def test_gpu_shards_loopback(world, krings, precision):
+    """several shards on one card, exchanged in-process: HIP shard plans + pack kernel"""
+    import torch
+    from fem_amd.dist import HipShardStepper
+    nu, nparts, steps = 24, 40, 20
+    part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
+    model = fa.default_model()
+    n0, c0 = fa.initial_condition(om.V, 3)
+    shards = [fa.Shard(part, r, world, krings) for r in range(world)]
+    steppers = [HipShardStepper(om, s, precision, model, n0[s.loc2glob], c0[s.loc2glob]) for s in shards]
+    budget = krings
+    for _ in range(steps):
+        if budget == 0:
+            sends = [st.pack(None).clone() for st in steppers]
+            torch.cuda.synchronize()
+            for r, st in enumerate(steppers):
+                ghost, pos = st.ghost_view(), 0
+                for q in range(world):
+                    cnt = int(shards[r].recv_counts[q])
+                    off = int(shards[q].send_counts[:r].sum())
+                    ghost[pos:pos + cnt] = sends[q][off:off + cnt]
+                    pos += cnt
+            budget = krings
+        for st in steppers:
+            st.step(1, dt, model, None)
+        budget -= 1
+    tol = 1e-11 if precision == "f64" else 1e-5
+    for s, st in zip(shards, steppers):
+        n, c = st.get_owned()
+        assert rel_l2(n, n_ref[s.own_begin:s.own_end]) <= tol and rel_l2(c, c_ref[s.own_begin:s.own_end]) <= tol
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_gloo(tmp_path):
+    """ShardedRun with the HIP stepper as 2 processes sharing the card (exchange staged via gloo)"""
+    nu, nparts, steps = 16, 12, 11
+    part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
+    res = launch(2, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=4, steps=steps, precision="f64")
+    for r in res:
+        b, e = int(r["own_begin"]), int(r["own_end"])
+        assert rel_l2(r["n"], n_ref[b:e]) <= 1e-11 and rel_l2(r["c"], c_ref[b:e]) <= 1e-11
