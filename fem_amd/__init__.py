@@ -145,7 +145,7 @@ class Mesh:
         self.precision = None
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.fem_mesh_destroy(self.h)
             self.h = None
 
@@ -247,7 +247,7 @@ class RefLayout:
         self.maxV, self.W, self.maxF, self.n_halo = a.value, b.value, c.value, d.value
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.fem_ref_layout_destroy(self.h)
             self.h = None
 
@@ -280,7 +280,7 @@ class RefDevice:
         self.h, self.V = h, part.ordered.V
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.fem_ref_device_destroy(self.h)
             self.h = None
 
@@ -349,7 +349,7 @@ class Shard:
         self.recv_counts = np.ctypeslib.as_array(rc, shape=(nranks,)).copy()
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.fem_shard_destroy(self.h)
             self.h = None
 
@@ -372,7 +372,7 @@ class Plan:
         _check(lib.fem_plan_pack_halo(self.h, C.c_uint64(dst_ptr), vp(stream or 0)))
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.fem_plan_destroy(self.h)
             self.h = None
 

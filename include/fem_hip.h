@@ -123,7 +123,7 @@ void fem_mesh_topology(const fem_mesh *m, const int32_t **opp, const fem_uint **
  * flat-array form.  Outputs: perm_v[V], perm_f[F] (new position of each old
  * index), node_parts[n+1], element_parts[n+2] (last bucket = cut faces), and
  * the reordered mesh.  Returns the edge cut (>= 0) or a negative fem_status.
- * METIS is replaced by a deterministic Hilbert-curve k-way split. */
+ * METIS is replaced by a deterministic recursive-coordinate-bisection k-way split. */
 int fem_partition(const fem_mesh *original, int n, int64_t *perm_v, int64_t *perm_f,
                   fem_uint *node_parts, fem_uint *element_parts, fem_mesh **ordered);
 /* The stage METIS_PartMeshDual occupied (partitioning_common.cpp:51-58):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generates the committed fixtures under tests/golden/ (run from the repo root, CPU only).
 
-  partition_golden.npz : vertex -> part of the product's Hilbert split (regression pin of the
+  partition_golden.npz : vertex -> part of the product's recursive-coordinate-bisection split (regression pin of the
                          stage METIS occupied in the reference; there is no reference output
                          to compare with: METIS is absent and its version unpinned).
   step_golden.npz      : (n, c) after {1, 10, 100} steps from the seeded IC, computed by the

@@ -106,7 +106,7 @@ def test_partition_contract_bit_exact(name, n):
 
 
 def test_partition_golden_fixture():
-    """regression pin of the Hilbert split (the stage METIS occupied): committed vertex parts of
+    """regression pin of the RCB split (the stage METIS occupied): committed vertex parts of
     the nu=9 sphere (n=7) and the strip (n=3); generator: tests/golden/make_golden.py"""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "partition_golden.npz"))
     for name, n in (("ico9", 7), ("strip", 3)):
