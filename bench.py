@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("FEM_BENCH_WORKLOAD", "sphere16m"), choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--fuse", type=int, default=int(os.environ.get("FEM_FUSE_STEPS", "4")),
+                    help="time steps fused per launch (0 = single-step sliced-ELL kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -83,13 +85,15 @@ def main():
     pts, tri = fa.make_icosphere(wl["nu"], 0.1)
     mesh = fa.Mesh(pts, tri)
     V_total = mesh.V
-    nparts = max(world, V_total // wl["verts_per_part"])
+    # fused tiles: partition size such that a partition + (fuse-1) rings fits the register tile
+    tile_n0 = int(os.environ.get("FEM_TILE_N0", "620"))
+    nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     if world > 1:
         from fem_amd import dist as fdist
         runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision)
     else:
         from fem_amd import dist as fdist
-        runner = fdist.SingleRun(mesh, nparts, args.precision)
+        runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse)
     del pts, tri, mesh
     t_host = time.perf_counter() - t_host
 
@@ -117,9 +121,11 @@ def main():
 
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
-        kernel_ms = dev_ms / args.steps                     # average launch duration, device events
+        spl = getattr(runner, "steps_per_launch", 1)
+        launches = -(-args.steps // spl)
+        kernel_ms = dev_ms / launches                       # average launch duration, device events
         v_per_launch = runner.vertices_per_launch           # owned vertices this rank advances per launch
-        achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch / (kernel_ms * 1e-3) / 1e9
+        achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch * (args.steps / launches) / (kernel_ms * 1e-3) / 1e9
         out = {
             "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -129,10 +135,12 @@ def main():
                                    "reaction-diffusion explicit Euler, seeded random IC"
                                    % (args.workload, wl["nu"], V_total, 2 * V_total - 4, nparts),
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
+                       "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": runner.measured_traffic(),
                          "alg_bytes_per_vertex_step": ALG_BYTES_PER_VERTEX_STEP, "avg_launch_ms": kernel_ms,
+                         "time_steps_per_launch": args.steps / launches,
                          "layout_bytes_per_launch": runner.layout_bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:

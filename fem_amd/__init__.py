@@ -357,16 +357,32 @@ class Shard:
 class Plan:
     """Native plan: sliced-ELL operator + ping-pong state on the device."""
 
-    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None):
+    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None, part=None, ksteps=0):
+        """ksteps > 0 (with part = the Partition of `ordered`): fused-tile layout, up to ksteps time
+        steps per launch; otherwise the sliced-ELL layout, one step per launch"""
         h = vp()
         mp = C.byref(model) if model is not None else None
-        if shard is None:
+        self.ksteps = ksteps
+        if ksteps > 0:
+            _check(lib.fem_plan_create_tiled(ordered.h, C.c_int(part.n), _ptr(part.node_parts, u32p),
+                                             shard.h if shard is not None else None, C.c_int(precision), mp,
+                                             C.c_int(ksteps), C.byref(h)))
+            self.V = shard.n_local if shard is not None else ordered.V
+        elif shard is None:
             _check(lib.fem_plan_create(ordered.h, C.c_int(precision), mp, C.byref(h)))
             self.V = ordered.V
         else:
             _check(lib.fem_plan_create_shard(ordered.h, shard.h, C.c_int(precision), mp, C.byref(h)))
             self.V = shard.n_local
         self.h, self.precision = h, precision
+
+    def tile_info(self):
+        k, thr, rpt = C.c_int(), C.c_int(), C.c_int()
+        nt, ml, rows = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _check(lib.fem_plan_tile_info(self.h, C.byref(k), C.byref(nt), C.byref(ml), C.byref(rows), C.byref(thr),
+                                      C.byref(rpt)))
+        return dict(ksteps=k.value, ntiles=nt.value, max_local=ml.value, rows_loaded=rows.value,
+                    threads=thr.value, rows_per_thread=rpt.value)
 
     def pack_halo(self, dst_ptr, stream=None):
         _check(lib.fem_plan_pack_halo(self.h, C.c_uint64(dst_ptr), vp(stream or 0)))

@@ -8,7 +8,9 @@
 //                      64-row slice, no atomics, no LDS.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -148,6 +150,24 @@ template <> struct Vec<double> { typedef double2 t2; typedef double4 t4; };
 // bn = base value the stored n is a deviation from; cden = 1/(1+bn); nMaxOff = nMax - bn
 template <typename T> struct ModelT { T nMaxOff, D, r, alpha, S, dt, bn, cden; };
 
+// Reaction + explicit Euler + clamp (FEM_common.cu:153-165) on deviation-form state.
+// The buffers hold deviations (n - bn, c - bn/(1+bn)) from the homogeneous state: differences
+// are unchanged, n(nMax - n) = n((nMax - bn) - dev) and n/(1+n) - c = dev_n/((1+n)(1+bn)) - dev_c
+// are exact rewrites, and the update no longer rounds at the magnitude of n itself.
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t2 reaction_update(typename Vec<T>::t2 s, T lapn, T lapc, T gnx, T gny,
+                                                               T gnz, T gcx, T gcy, T gcz, const ModelT<T> &m) {
+  const T n = m.bn + s.x;
+  const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
+  const T dauN = m.D * lapn - m.alpha * n * lapc - m.alpha * dotP + m.S * m.r * n * (m.nMaxOff - s.x);
+  const T dauC = lapc + m.S * (s.x * m.cden / (1 + n) - s.y);
+  const T un = m.dt * dauN + s.x, uc = m.dt * dauC + s.y;
+  typename Vec<T>::t2 o;
+  o.x = un + m.bn > 0 ? un : -m.bn;                 // max(0, n) of FEM_common.cu:164-165
+  o.y = uc + m.bn * m.cden > 0 ? uc : -(m.bn * m.cden);
+  return o;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void sell_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
@@ -177,18 +197,103 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
     gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
     gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
   }
-  // The buffers hold deviations (n - bn, c - bn/(1+bn)) from the homogeneous state: differences
-  // are unchanged, n(nMax - n) = n((nMax - bn) - dev) and n/(1+n) - c = dev_n/((1+n)(1+bn)) - dev_c
-  // are exact rewrites, and the update no longer rounds at the magnitude of n itself.
-  const T n = m.bn + s.x;
-  const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
-  const T dauN = m.D * lapn - m.alpha * n * lapc - m.alpha * dotP + m.S * m.r * n * (m.nMaxOff - s.x);
-  const T dauC = lapc + m.S * (s.x * m.cden / (1 + n) - s.y);
-  const T un = m.dt * dauN + s.x, uc = m.dt * dauC + s.y;
-  T2 o;
-  o.x = un + m.bn > 0 ? un : -m.bn;                 // max(0, n) of FEM_common.cu:164-165
-  o.y = uc + m.bn * m.cden > 0 ? uc : -(m.bn * m.cden);
+  const T2 o = reaction_update<T>(s, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
   if (v < V) dst[v] = o;
+}
+
+// ---------------------------------------------------------------------------
+// Fused k-step kernel.  One workgroup per tile (pack.cpp:packTileLayout): the tile's owned rows
+// plus k rings of neighbours are staged in LDS (two ping-pong buffers of m[k] pairs), the
+// operator rows of the first m[k-1] local rows are loaded ONCE into registers (thread t holds rows
+// t, t+TPB, ...: R rows x W entries x (float4 coef + 16-bit local column id)), and the workgroup
+// takes up to k time steps before writing its owned rows back: step s recomputes rows
+// [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
+// vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
+// ---------------------------------------------------------------------------
+template <typename T, int TPB, int R, int W, int MINW>
+__global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
+    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
+    const typename Vec<T>::t4 *__restrict__ coef, uint ntiles, uint maxLocal, int nsteps, ModelT<T> m) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  extern __shared__ __align__(16) unsigned char tile_smem[];
+  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
+  const uint tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);
+  const uint *mt = meta + 16 * (size_t)tile;
+  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], k = mt[4];
+  const uint n0 = mt[5], mk = mt[5 + k];
+  T2 *cur = reinterpret_cast<T2 *>(tile_smem);
+  T2 *nxt = cur + maxLocal;
+  const uint t = threadIdx.x;
+
+  // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
+  const T4 *__restrict__ tcoef = coef + roff;
+  const uint *__restrict__ tidx = idx2 + (roff >> 1);
+  // Every load below is unconditional with a clamped index (no branch => no wait at a branch
+  // merge), so the whole prologue is in flight at once: R*(W + W/2) operator loads, then the
+  // ghost ids, then the state gathers; the first wait is the one in front of the LDS writes.
+  T4 cf[R][W];
+  uint ix[R][W / 2];
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    const uint r = min(t + TPB * q, rpad - 1);         // rows in [rows, rpad) are zero padding
+#pragma unroll
+    for (int w = 0; w < W; w++) cf[q][w] = tcoef[w * rpad + r];
+#pragma unroll
+    for (int w = 0; w < W / 2; w++) ix[q][w] = tidx[w * rpad + r] * (uint)sizeof(T2);   // ids < 4096: both halves scale
+  }
+  constexpr int SU = 4;                                  // state slots per thread per pass
+  for (uint i0 = 0; i0 < mk; i0 += SU * TPB) {
+    uint gi[SU];
+    T2 sv[SU];
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      const uint g = (i >= n0 && i < mk) ? i - n0 : 0;   // ghost[] carries one pad element
+      gi[u] = ghost[goff + g];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      sv[u] = src[i < n0 ? base + i : gi[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      if (i < mk) cur[i] = sv[u];
+    }
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; s++) {
+    const uint lim = mt[5 + k - 1 - s];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const uint r = t + TPB * q;
+      if (r < lim) {
+        const T2 self = cur[r];
+        T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+#pragma unroll
+        for (int w = 0; w < W / 2; w++) asm volatile("" : "+v"(ix[q][w]));   // keep the unpacking in the loop, not in VGPRs
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+          const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);   // byte offset in the buffer
+          const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
+          const T4 c = cf[q][w];
+          const T dn = f.x - self.x, dc = f.y - self.y;
+          lapn += c.x * dn; lapc += c.x * dc;
+          gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+          gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+        }
+        nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
+    }
+    __syncthreads();
+    T2 *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  for (uint i = t; i < n0; i += TPB) dst[base + i] = cur[i];
 }
 
 // halo pack: dst[i] = state[send_idx[i]] (8 or 16 B per lane, coalesced stores)
@@ -218,6 +323,16 @@ size_t pitchFor(size_t widthBytes) { return (widthBytes + 511) / 512 * 512; }   
 // C-ABI, device half
 // ===========================================================================
 
+// Register-tile geometries of the fused kernel: threads per workgroup, rows per thread, minimum
+// waves per SIMD (sets the VGPR budget: 4 -> 128, 3 -> 168).  FEM_TILE_CONFIG picks one (tuning knob;
+// 0 = 512 x 2 is the measured best: no spills, 2 workgroups per CU, 1024 register-resident rows per tile).
+constexpr int kTileW = 6;
+constexpr fem_uint kTileMaxLocal = 4096;
+struct TileCfg { int tpb, r, minw; };
+constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}};
+constexpr int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
+
+
 struct fem_ref_device {
   int n = 0, V = 0;
   fem_uint maxV = 0, W = 0, maxF = 0, threads = 0, smem = 0;
@@ -234,11 +349,35 @@ struct fem_plan {
   fem_uint V = 0, nslices = 0, nblocks = 0;
   size_t entries = 0;
   DevBuf<fem_uint> slice_off, idx, send_idx;
+  // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
+  int ksteps = 0, tcfg = 0;
+  fem_uint ntiles = 0, maxLocal = 0;
+  uint64_t tile_rows = 0;
+  uint64_t tile_bytes = 0;
+  DevBuf<fem_uint> tmeta, tghost, tidx2;
+  void *tcoef = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
   void *state[2] = {nullptr, nullptr};   // deviations from (base_n, base_c), interleaved
   int cur = 0;
   double base_n = 1.0, base_c = 0.5;
 };
+
+template <typename T, int C>
+static hipError_t launchTile(fem_plan *p, const void *src, void *dst, int nsteps, const ModelT<T> &m, hipStream_t stream) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
+  constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : (TPB == 512 ? 2 : 1);
+  auto kern = tile_step_kernel<T, TPB, R, kTileW, MINW>;
+  const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(p->ntiles), dim3(TPB), lds, stream, (const T2 *)src, (T2 *)dst, p->tmeta.p,
+                     p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->ntiles, p->maxLocal, nsteps, m);
+  return hipSuccess;
+}
 
 extern "C" {
 
@@ -391,42 +530,81 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
 void fem_plan_destroy(fem_plan *p) {
   if (!p) return;
   p->slice_off.release(); p->idx.release(); p->send_idx.release();
+  p->tmeta.release(); p->tghost.release(); p->tidx2.release();
+  if (p->tcoef) (void)hipFree(p->tcoef);
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
   delete p;
 }
 
 static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int precision, const fem_model *model,
-                      fem_plan **out) {
-  if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64))
+                      int ksteps, int n, const fem_uint *node_parts, fem_plan **out) {
+  if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64) || ksteps < 0 || ksteps > 8)
     return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
+  if (ksteps > 0 && (!node_parts || n < 1)) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partition ranges missing");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");
-  fem::SellLayout L;
-  int rc = shard ? fem::packSellLayout(ordered->mesh, ordered->stats, L, shard->loc2glob.data(), (fem::uint)shard->loc2glob.size())
-                 : fem::packSellLayout(ordered->mesh, ordered->stats, L);
+  fem::RowOp op;
+  int rc = shard ? fem::buildRowOp(ordered->mesh, ordered->stats, op, shard->loc2glob.data(), (fem::uint)shard->loc2glob.size())
+                 : fem::buildRowOp(ordered->mesh, ordered->stats, op);
   if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh has no topology/stats or is too large");
+  fem::SellLayout L;
+  fem::TileLayout TL;
+  int tcfg = 0;
+  if (ksteps > 0) {
+    // tiles = this rank's partitions, then (shards only) the ghost rows in pieces
+    std::vector<std::pair<fem::uint, fem::uint>> ranges;
+    const fem::uint own_b = shard ? shard->own_begin : 0, own_e = shard ? shard->own_end : op.V;
+    for (int p = 0; p < n; p++)
+      if (node_parts[p] >= own_b && node_parts[p + 1] <= own_e && node_parts[p + 1] > node_parts[p])
+        ranges.push_back(std::make_pair(node_parts[p] - own_b, node_parts[p + 1] - own_b));
+    fem::uint covered = 0;
+    for (auto &r : ranges) covered += r.second - r.first;
+    if (covered != own_e - own_b) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partitions do not tile the owned range");
+    for (fem::uint g = own_e - own_b; g < op.V; g += 512) ranges.push_back(std::make_pair(g, std::min(op.V, g + 512)));
+    const char *cfgEnv = getenv("FEM_TILE_CONFIG");
+    tcfg = cfgEnv ? atoi(cfgEnv) : 0;
+    if (tcfg < 0 || tcfg >= kNumTileCfgs) return fail(FEM_ERR_INVALID, "FEM_TILE_CONFIG out of range");
+    rc = fem::packTileLayout(op, ranges, ksteps, kTileCfgs[tcfg].tpb, kTileCfgs[tcfg].r, kTileW, kTileMaxLocal, TL);
+    if (rc == FEM_ERR_LIMIT) return fail(rc, "fem_plan_create_tiled: a row has more than 6 neighbours (fused kernel limit)");
+    if (rc != FEM_OK) return fail(rc, "fem_plan_create_tiled: cannot tile");
+  } else {
+    rc = fem::packSellLayout(op, L);
+    if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh too large");
+  }
   fem_plan *p = new fem_plan();
   p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
-  p->precision = precision; p->V = L.V; p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4;
-  p->entries = L.idx.size();
+  p->precision = precision; p->V = op.V;
   const size_t sb = precision == FEM_PREC_F32 ? sizeof(float) : sizeof(double);
   hipError_t e = hipSuccess;
   auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
-  ok(p->slice_off.alloc(L.slice_off.size())) && ok(p->slice_off.upload(L.slice_off.data())) &&
-  ok(p->idx.alloc(L.idx.size())) && ok(p->idx.upload(L.idx.data())) &&
-  ok(hipMalloc(&p->coef, 4 * sb * (p->entries ? p->entries : 1))) &&
+  auto uploadCoef = [&](void **dev, const std::vector<double> &c) {
+    if (!ok(hipMalloc(dev, sb * (c.empty() ? 4 : c.size())))) return;
+    if (precision == FEM_PREC_F32) {
+      std::vector<float> c32(c.begin(), c.end());
+      ok(hipMemcpy(*dev, c32.data(), sizeof(float) * c32.size(), hipMemcpyHostToDevice));
+    } else {
+      ok(hipMemcpy(*dev, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice));
+    }
+  };
+  if (ksteps > 0) {
+    p->ksteps = ksteps; p->ntiles = TL.ntiles; p->maxLocal = TL.maxLocal; p->tcfg = tcfg; p->tile_rows = TL.rowSteps;
+    p->tile_bytes = (uint64_t)(TL.coef.size() / 4) * (4 * sb + 2) + (uint64_t)TL.ghost.size() * 4 + (uint64_t)TL.meta.size() * 4;
+    ok(p->tmeta.alloc(TL.meta.size())) && ok(p->tmeta.upload(TL.meta.data())) &&
+    ok(p->tghost.alloc(TL.ghost.size())) && (TL.ghost.empty() || ok(p->tghost.upload(TL.ghost.data()))) &&
+    ok(p->tidx2.alloc(TL.idx2.size())) && ok(p->tidx2.upload(TL.idx2.data()));
+    uploadCoef(&p->tcoef, TL.coef);
+  } else {
+    p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4; p->entries = L.idx.size();
+    ok(p->slice_off.alloc(L.slice_off.size())) && ok(p->slice_off.upload(L.slice_off.data())) &&
+    ok(p->idx.alloc(L.idx.size())) && ok(p->idx.upload(L.idx.data()));
+    uploadCoef(&p->coef, L.coef);
+  }
   ok(hipMalloc(&p->state[0], 2 * sb * p->V)) && ok(hipMalloc(&p->state[1], 2 * sb * p->V));
   if (e == hipSuccess && shard)
     ok(p->send_idx.alloc(shard->send_idx.size())) && (shard->send_idx.empty() || ok(p->send_idx.upload(shard->send_idx.data())));
   if (e == hipSuccess) {
-    if (precision == FEM_PREC_F32) {
-      std::vector<float> c32(L.coef.begin(), L.coef.end());
-      ok(hipMemcpy(p->coef, c32.data(), sizeof(float) * c32.size(), hipMemcpyHostToDevice));
-    } else {
-      ok(hipMemcpy(p->coef, L.coef.data(), sizeof(double) * L.coef.size(), hipMemcpyHostToDevice));
-    }
     ok(hipMemset(p->state[0], 0, 2 * sb * p->V));
     ok(hipMemset(p->state[1], 0, 2 * sb * p->V));
   }
@@ -436,13 +614,19 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
 }
 
 int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out) {
-  return planCreate(ordered, nullptr, precision, model, out);
+  return planCreate(ordered, nullptr, precision, model, 0, 0, nullptr, out);
+}
+
+int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts, const fem_shard *shard,
+                          int precision, const fem_model *model, int ksteps, fem_plan **out) {
+  if (ksteps < 1) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: ksteps must be 1..8");
+  return planCreate(ordered, shard ? &shard->s : nullptr, precision, model, ksteps, n, node_parts, out);
 }
 
 int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int precision, const fem_model *model,
                           fem_plan **out) {
   if (!shard) return fail(FEM_ERR_INVALID, "fem_plan_create_shard: null shard");
-  return planCreate(ordered, &shard->s, precision, model, out);
+  return planCreate(ordered, &shard->s, precision, model, 0, 0, nullptr, out);
 }
 
 int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream) {
@@ -493,21 +677,39 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
   if (!p || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_plan_run: bad argument");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
+  ModelT<float> mf = {(float)(model->nMax - p->base_n), (float)model->D, (float)model->r, (float)model->alpha,
+                      (float)model->S, (float)dt, (float)p->base_n, (float)(1.0 / (1.0 + p->base_n))};
+  ModelT<double> md = {model->nMax - p->base_n, model->D, model->r, model->alpha, model->S, dt, p->base_n,
+                       1.0 / (1.0 + p->base_n)};
+  if (p->ksteps > 0) {                       // fused tiles: up to ksteps time steps per launch
+    for (int done = 0; done < nsteps;) {
+      const int c = std::min(p->ksteps, nsteps - done);
+      void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
+      hipError_t e = hipSuccess;
+#define FEM_TILE_CASE(C)                                                                         \
+  case C:                                                                                        \
+    e = p->precision == FEM_PREC_F32 ? launchTile<float, C>(p, src, dst, c, mf, (hipStream_t)stream) \
+                                     : launchTile<double, C>(p, src, dst, c, md, (hipStream_t)stream); \
+    break;
+      switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) }
+#undef FEM_TILE_CASE
+      if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "tile_step_kernel launch", e);
+      p->cur ^= 1;
+      done += c;
+    }
+    HIP_TRY(hipGetLastError());
+    return FEM_OK;
+  }
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
-    if (p->precision == FEM_PREC_F32) {
-      ModelT<float> m = {(float)(model->nMax - p->base_n), (float)model->D, (float)model->r, (float)model->alpha,
-                         (float)model->S, (float)dt, (float)p->base_n, (float)(1.0 / (1.0 + p->base_n))};
+    if (p->precision == FEM_PREC_F32)
       hipLaunchKernelGGL(sell_step_kernel<float>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
-                         p->V, p->nslices, p->nblocks, m);
-    } else {
-      ModelT<double> m = {model->nMax - p->base_n, model->D, model->r, model->alpha, model->S, dt, p->base_n,
-                          1.0 / (1.0 + p->base_n)};
+                         p->V, p->nslices, p->nblocks, mf);
+    else
       hipLaunchKernelGGL(sell_step_kernel<double>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const double2 *)src, (double2 *)dst, p->slice_off.p, p->idx.p, (const double4 *)p->coef,
-                         p->V, p->nslices, p->nblocks, m);
-    }
+                         p->V, p->nslices, p->nblocks, md);
     p->cur ^= 1;
   }
   HIP_TRY(hipGetLastError());
@@ -525,9 +727,22 @@ int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, i
   return FEM_OK;
 }
 
+int fem_plan_tile_info(const fem_plan *p, int *ksteps, fem_uint *ntiles, fem_uint *max_local, uint64_t *rows_loaded,
+                       int *threads, int *rows_per_thread) {
+  if (!p) return fail(FEM_ERR_INVALID, "fem_plan_tile_info: null");
+  if (ksteps) *ksteps = p->ksteps;
+  if (ntiles) *ntiles = p->ntiles;
+  if (max_local) *max_local = p->maxLocal;
+  if (rows_loaded) *rows_loaded = p->tile_rows;
+  if (threads) *threads = p->ksteps ? kTileCfgs[p->tcfg].tpb : 256;
+  if (rows_per_thread) *rows_per_thread = p->ksteps ? kTileCfgs[p->tcfg].r : 1;
+  return FEM_OK;
+}
+
 uint64_t fem_plan_operator_bytes(const fem_plan *p) {
   if (!p) return 0;
   const size_t sb = p->precision == FEM_PREC_F32 ? 4 : 8;
+  if (p->ksteps > 0) return p->tile_bytes;
   return (uint64_t)p->entries * (4 + 4 * sb) + (uint64_t)(p->nslices + 1) * 4;
 }
 

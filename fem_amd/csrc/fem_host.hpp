@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/fem_hip.h"
@@ -120,8 +121,28 @@ struct SellLayout {
   std::vector<uint> idx;                     // [entries]
   std::vector<double> coef;                  // [4*entries] (w, Cx, Cy, Cz)
 };
-int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &out,
-                   const uint *loc2glob = nullptr, uint nloc = 0);
+// Folded operator in CSR form over local rows (whole mesh, or a shard's loc2glob list).
+struct RowOp {
+  uint V = 0;
+  std::vector<uint> rowptr, col;             // [V+1], [nnz] local column ids, ascending global order
+  std::vector<double> coef;                  // [4*nnz] (w, Cx, Cy, Cz)
+};
+int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &out, const uint *loc2glob = nullptr,
+               uint nloc = 0);
+int packSellLayout(const RowOp &op, SellLayout &out);
+
+// Tiles of the fused k-step kernel (pack.cpp).
+struct TileLayout {
+  int ksteps = 0;
+  uint T = 0, R = 0, W = 0, ntiles = 0, maxLocal = 0;
+  uint64_t rowSteps = 0;                     // sum over tiles of m[k-1] (rows loaded per launch)
+  std::vector<uint> meta;                    // [ntiles][16]
+  std::vector<uint> ghost;                   // row ids of the ring rows of every tile
+  std::vector<uint> idx2;                    // packed 16-bit local column ids
+  std::vector<double> coef;                  // [4*entries]
+};
+int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ranges, int ksteps, uint T, uint R,
+                   uint W, uint maxLocal, TileLayout &out);
 
 // One rank's share of an ordered mesh: a contiguous range of partitions (hence of vertices),
 // plus the ghost vertices within `krings` edges of it, and who sends what to whom.

@@ -86,7 +86,7 @@ int packRefLayout(const SimpleTriMesh &m, const MeshStats &s, int n, const uint 
   return FEM_OK;
 }
 
-// Native layout.  Row v, entry for neighbour j (half-edge h: v -> j):
+// Folded operator rows.  Row v, entry for neighbour j (half-edge h: v -> j):
 //   w     = wHej[h]                                  (Laplacian, difference form)
 //   C_vj  = (1/Theta_v) * sum over the <=2 faces f on edge (v,j) of
 //           theta_{v,f} * grad(phi_j) on f           (vertex gradient, folded)
@@ -94,12 +94,11 @@ int packRefLayout(const SimpleTriMesh &m, const MeshStats &s, int n, const uint 
 // which equal the reference's fn*wVtx + sum fn_j*wHej (wVtx = -sum wHej,
 // mesh_function.cpp:263-265) and its angle-weighted mean of face gradients
 // (mesh_function.h:35-110) because the hat gradients of a face sum to zero.
-// Rows are padded to the slice width with (idx = own row, coef = 0).
 // With a row list (loc2glob[nloc], a shard's owned vertices followed by its ghosts) row r holds
 // the operator row of global vertex loc2glob[r] with column ids remapped to local ones;
 // neighbours outside the list are dropped (only the outermost ghost ring has any, and its rows
 // are never consumed: DESIGN.md "Multi-GPU").
-int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o, const uint *loc2glob, uint nloc) {
+int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint *loc2glob, uint nloc) {
   const uint Vg = m.n_vertices();
   const int H3 = 3 * (int)m.n_faces();
   if (m.H == 0 || s.precision < 0 || Vg == 0) return FEM_ERR_INVALID;
@@ -113,21 +112,14 @@ int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o, co
       glob2loc[loc2glob[r]] = (int32_t)r;
     }
   }
-  auto G = [&](uint r) { return loc2glob ? loc2glob[r] : r; };
-  o = SellLayout();
+  o = RowOp();
   o.V = V;
-  o.nslices = (V + 63) / 64;
-  o.slice_off.assign(o.nslices + 1, 0);
-  for (uint sl = 0; sl < o.nslices; sl++) {
-    uint w = 0;
-    for (uint v = sl * 64; v < std::min(V, sl * 64 + 64); v++) w = std::max(w, (uint)(m.rowptr[G(v) + 1] - m.rowptr[G(v)]));
-    uint64_t next = (uint64_t)o.slice_off[sl] + (uint64_t)w * 64;
-    if (next > 0xffffffffull) return FEM_ERR_LIMIT;
-    o.slice_off[sl + 1] = (uint)next;
-  }
-  const size_t entries = o.slice_off[o.nslices];
-  o.idx.resize(entries);
-  o.coef.assign(4 * entries, 0.0);
+  o.rowptr.assign((size_t)V + 1, 0);
+  size_t nnzMax = 0;
+  for (uint r = 0; r < V; r++) { const uint v = loc2glob ? loc2glob[r] : r; nnzMax += m.rowptr[v + 1] - m.rowptr[v]; }
+  if (nnzMax > 0xffffffffull) return FEM_ERR_LIMIT;
+  o.col.reserve(nnzMax);
+  o.coef.reserve(4 * nnzMax);
 
   auto hatGrad = [&](int f, int corner, double *g) {   // corner 0 (a): gradVec12, 1 (b): gradVec13, 2 (c): -(both)
     for (int k = 0; k < 3; k++) {
@@ -136,6 +128,62 @@ int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o, co
     }
   };
 
+  for (uint row = 0; row < V; row++) {
+    const uint v = loc2glob ? loc2glob[row] : row;
+    double theta = 0;
+    for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+      const int h = m.row_he[e];
+      if (h < H3) theta += s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
+    }
+    for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+      uint lc = m.col[e];
+      if (loc2glob) {
+        const int32_t l = glob2loc[m.col[e]];
+        if (l < 0) continue;                       // neighbour outside the shard
+        lc = (uint)l;
+      }
+      const int h = m.row_he[e], ho = m.opp[h];
+      double C[3] = {0, 0, 0}, g[3];
+      if (theta > 0) {
+        if (h < H3) {           // face left of v->j: v = corner h%3, j = next corner
+          hatGrad(h / 3, (h % 3 + 1) % 3, g);
+          const double a = s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
+          for (int d = 0; d < 3; d++) C[d] += a * g[d];
+        }
+        if (ho < H3) {          // face left of j->v: j = corner ho%3, angle at v = meshAngle[ho]
+          hatGrad(ho / 3, ho % 3, g);
+          const double a = s.meshAngle[ho];
+          for (int d = 0; d < 3; d++) C[d] += a * g[d];
+        }
+        for (int d = 0; d < 3; d++) C[d] /= theta;
+      }
+      o.col.push_back(lc);
+      o.coef.push_back(s.wHej[h]);
+      o.coef.push_back(C[0]); o.coef.push_back(C[1]); o.coef.push_back(C[2]);
+    }
+    o.rowptr[row + 1] = (uint)o.col.size();
+  }
+  return FEM_OK;
+}
+
+// Native layout 1: sliced ELL, 64 rows per slice; rows padded to the slice width with
+// (idx = own row, coef = 0).
+int packSellLayout(const RowOp &op, SellLayout &o) {
+  const uint V = op.V;
+  o = SellLayout();
+  o.V = V;
+  o.nslices = (V + 63) / 64;
+  o.slice_off.assign(o.nslices + 1, 0);
+  for (uint sl = 0; sl < o.nslices; sl++) {
+    uint w = 0;
+    for (uint v = sl * 64; v < std::min(V, sl * 64 + 64); v++) w = std::max(w, op.rowptr[v + 1] - op.rowptr[v]);
+    uint64_t next = (uint64_t)o.slice_off[sl] + (uint64_t)w * 64;
+    if (next > 0xffffffffull) return FEM_ERR_LIMIT;
+    o.slice_off[sl + 1] = (uint)next;
+  }
+  const size_t entries = o.slice_off[o.nslices];
+  o.idx.resize(entries);
+  o.coef.assign(4 * entries, 0.0);
   for (uint sl = 0; sl < o.nslices; sl++) {
     const uint off = o.slice_off[sl], width = (o.slice_off[sl + 1] - off) / 64;
     for (uint lane = 0; lane < 64; lane++) {
@@ -143,42 +191,107 @@ int packSellLayout(const SimpleTriMesh &m, const MeshStats &s, SellLayout &o, co
       const uint self = row < V ? row : V - 1;
       for (uint k = 0; k < width; k++) o.idx[off + (size_t)k * 64 + lane] = self;
       if (row >= V) continue;
-      const uint v = G(row);
-      double theta = 0;
-      for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
-        const int h = m.row_he[e];
-        if (h < H3) theta += s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
-      }
       uint k = 0;
-      for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++, k++) {
-        const int h = m.row_he[e], ho = m.opp[h];
-        double C[3] = {0, 0, 0}, g[3];
-        if (theta > 0) {
-          if (h < H3) {           // face left of v->j: v = corner h%3, j = next corner
-            hatGrad(h / 3, (h % 3 + 1) % 3, g);
-            const double a = s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
-            for (int d = 0; d < 3; d++) C[d] += a * g[d];
-          }
-          if (ho < H3) {          // face left of j->v: j = corner ho%3, angle at v = meshAngle[ho]
-            hatGrad(ho / 3, ho % 3, g);
-            const double a = s.meshAngle[ho];
-            for (int d = 0; d < 3; d++) C[d] += a * g[d];
-          }
-          for (int d = 0; d < 3; d++) C[d] /= theta;
-        }
+      for (uint e = op.rowptr[row]; e < op.rowptr[row + 1]; e++, k++) {
         const size_t pos = off + (size_t)k * 64 + lane;
-        if (loc2glob) {
-          const int32_t lc = glob2loc[m.col[e]];
-          if (lc < 0) continue;                    // neighbour outside the shard: entry stays (self, 0)
-          o.idx[pos] = (uint)lc;
-        } else {
-          o.idx[pos] = m.col[e];
-        }
-        o.coef[4 * pos] = s.wHej[h];
-        o.coef[4 * pos + 1] = C[0]; o.coef[4 * pos + 2] = C[1]; o.coef[4 * pos + 3] = C[2];
+        o.idx[pos] = op.col[e];
+        for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)e + d];
       }
     }
   }
+  return FEM_OK;
+}
+
+// Native layout 2: tiles for the fused k-step kernel.  A tile = a contiguous range of rows (a
+// partition, or a piece of one when the partition does not fit) that the kernel advances k steps
+// in one launch, plus the k rings of rows around it: local list = owned rows, then ring 1, ...,
+// ring k (each ring ascending).  m[j] = number of local rows within j edges of the owned range.
+// The kernel keeps the state of all m[k] local rows in LDS and the operator rows of the first
+// m[k-1] in registers (thread t holds rows t, t+T, ..., at most R of them), so a tile must
+// satisfy m[k-1] <= T*R and m[k] <= maxLocal; ranges that do not are split in halves.
+// Per tile: meta[16] = {base, ghost_off, row_off, rows_pad, k, m[0..k]};
+//   ghost[ghost_off + i]            = row id of local row m[0]+i               (i < m[k]-m[0])
+//   idx2[(row_off + (w/2)*rows_pad*2)/2 ...]  see below
+//   coef[row_off + w*rows_pad + r]  = (w, Cx, Cy, Cz) of entry w of local row r (r < m[k-1])
+//   idx2[row_off/2 + (w/2)*rows_pad + r] = local ids of entries w, w+1 of row r, 16 bits each
+// (padding entries: own local id, coef 0).  rows_pad = m[k-1] rounded up to 64; row_off is even.
+int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ranges, int ksteps, uint T, uint R,
+                   uint W, uint maxLocal, TileLayout &o) {
+  if (ksteps < 1 || ksteps > 8 || (W & 1) || W == 0 || T == 0 || R == 0 || maxLocal > 65535) return FEM_ERR_INVALID;
+  const uint V = op.V;
+  for (uint v = 0; v < V; v++)
+    if (op.rowptr[v + 1] - op.rowptr[v] > W) return FEM_ERR_LIMIT;      // row wider than the register tile
+  o = TileLayout();
+  o.ksteps = ksteps; o.T = T; o.R = R; o.W = W;
+  std::vector<std::pair<uint, uint>> work(ranges.rbegin(), ranges.rend());
+  std::vector<uint> stamp(V, 0xffffffffu), local;
+  std::vector<uint> locId(V, 0);
+  uint tileNo = 0;
+  while (!work.empty()) {
+    const uint b = work.back().first, e = work.back().second;
+    work.pop_back();
+    if (e <= b) continue;
+    // rings by breadth-first search from the owned range
+    local.clear();
+    uint m[9] = {0};
+    for (uint v = b; v < e; v++) { stamp[v] = tileNo; local.push_back(v); }
+    m[0] = e - b;
+    size_t frontB = 0;
+    bool fits = true;
+    for (int ring = 1; ring <= ksteps; ring++) {
+      const size_t frontE = local.size();
+      for (size_t i = frontB; i < frontE; i++) {
+        const uint v = local[i];
+        for (uint q = op.rowptr[v]; q < op.rowptr[v + 1]; q++) {
+          const uint u = op.col[q];
+          if (stamp[u] != tileNo) { stamp[u] = tileNo; local.push_back(u); }
+        }
+      }
+      std::sort(local.begin() + frontE, local.end());
+      frontB = frontE;
+      m[ring] = (uint)local.size();
+      if (ring == ksteps - 1 && m[ring] > T * R) fits = false;   // rows held in registers
+      if (m[ring] > maxLocal) fits = false;                      // rows held in LDS
+      if (!fits) break;
+    }
+    if (ksteps == 1 && m[0] > T * R) fits = false;
+    tileNo++;
+    if (tileNo == 0xffffffffu) return FEM_ERR_LIMIT;
+    if (!fits) {
+      if (e - b < 2) return FEM_ERR_LIMIT;
+      const uint mid = b + (e - b) / 2;
+      work.push_back(std::make_pair(mid, e));
+      work.push_back(std::make_pair(b, mid));
+      continue;
+    }
+    for (uint i = 0; i < local.size(); i++) locId[local[i]] = i;
+    const uint rows = m[ksteps - 1], rowsPad = (rows + 63) / 64 * 64;
+    const size_t rowOff = o.coef.size() / 4;
+    if (rowOff + (size_t)W * rowsPad > 0xffffffffull) return FEM_ERR_LIMIT;
+    uint meta[16] = {b, (uint)o.ghost.size(), (uint)rowOff, rowsPad, (uint)ksteps};
+    for (int j = 0; j <= ksteps; j++) meta[5 + j] = m[j];
+    o.meta.insert(o.meta.end(), meta, meta + 16);
+    o.ghost.insert(o.ghost.end(), local.begin() + m[0], local.end());
+    o.coef.resize(4 * (rowOff + (size_t)W * rowsPad), 0.0);
+    o.idx2.resize((rowOff + (size_t)W * rowsPad) / 2, 0u);
+    for (uint r = 0; r < rowsPad; r++) {
+      uint ids[16];
+      for (uint w = 0; w < W; w++) ids[w] = r < rows ? r : 0;
+      if (r < rows) {
+        const uint v = local[r];
+        uint w = 0;
+        for (uint q = op.rowptr[v]; q < op.rowptr[v + 1]; q++, w++) {
+          ids[w] = locId[op.col[q]];
+          for (int d = 0; d < 4; d++) o.coef[4 * (rowOff + (size_t)w * rowsPad + r) + d] = op.coef[4 * (size_t)q + d];
+        }
+      }
+      for (uint w = 0; w < W; w += 2) o.idx2[rowOff / 2 + (size_t)(w / 2) * rowsPad + r] = ids[w] | (ids[w + 1] << 16);
+    }
+    o.maxLocal = std::max(o.maxLocal, m[ksteps]);
+    o.ntiles++;
+    o.rowSteps += rows;
+  }
+  o.ghost.push_back(0);            // pad: the kernel reads ghost[goff] even for tiles without rings
   return FEM_OK;
 }
 

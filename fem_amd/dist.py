@@ -13,20 +13,21 @@ _PROFILES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 
 class SingleRun:
     """partition -> reorder -> assemble (host, once) -> native plan; seeded IC of main.cpp:178-186"""
-    kernel_name = "sell_step_kernel"
-
-    def __init__(self, mesh, nparts, precision="f32", seed=1):
+    def __init__(self, mesh, nparts, precision="f32", seed=1, ksteps=0):
+        self.ksteps = ksteps
+        self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
         self.part = mesh.partition(nparts)
         om = self.part.ordered
         om.init_stats(fa.PREC_F64)
         self.dt = 0.1 * om.stats()["maxEdgeLen"] ** 2          # main.cpp:188
         self.model = fa.default_model()
         self.precision = precision
-        self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64)
+        self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, part=self.part, ksteps=ksteps)
         n0, c0 = fa.initial_condition(om.V, seed)
         self.plan.set_state(n0, c0)
         self.V = om.V
-        self.vertices_per_launch = om.V
+        self.vertices_per_launch = om.V                         # per time step
+        self.steps_per_launch = max(1, ksteps)
         sb = 4 if precision == "f32" else 8
         self.layout_bytes_per_launch = self.plan.operator_bytes() + 4 * sb * om.V   # operator + state r/w
 

@@ -206,6 +206,20 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
  * given different constants later; the rewrite stays exact for any of them. */
 typedef struct fem_plan fem_plan;
 int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out);
+/* Same operator in the fused-tile layout: every workgroup stages one partition (+ ksteps rings
+ * of neighbours) in LDS, keeps its operator rows in registers and takes up to `ksteps` time
+ * steps per launch (fused multi-step kernel; 1 <= ksteps <= 8).  n/node_parts = the partition
+ * ranges of the ordered mesh (partitioning_common.h:3-9 outputs); shard may be NULL.  Fails with
+ * FEM_ERR_LIMIT on meshes with a vertex of valence > 6 (use fem_plan_create there).
+ * fem_plan_run on such a plan issues ceil(nsteps / ksteps) launches. */
+int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts,
+                          const struct fem_shard *shard, int precision, const fem_model *model,
+                          int ksteps, fem_plan **out);
+/* geometry of a tiled plan: fused steps, tile count, largest tile (rows staged in LDS), operator
+ * rows loaded per launch (sum over tiles), workgroup size and rows per thread; ksteps = 0 for a
+ * sliced-ELL plan.  Any out-pointer may be NULL. */
+int fem_plan_tile_info(const fem_plan *p, int *ksteps, fem_uint *ntiles, fem_uint *max_local,
+                       uint64_t *rows_loaded, int *threads, int *rows_per_thread);
 void fem_plan_destroy(fem_plan *p);
 int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn);
 int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn);

@@ -193,3 +193,40 @@ def test_native_plan_full_size_properties():
     plan64.run(20, dt, model)
     n64, c64 = plan64.get_state()
     assert rel_l2(outs[0][0], n64) <= TOL_F32 and rel_l2(outs[0][1], c64) <= TOL_F32
+
+
+@pytest.mark.parametrize("make,nparts,ksteps,steps", [
+    (lambda n: sphere_case(32, n), 52, 4, 10),        # 10 = 4 + 4 + 2: a short last launch
+    (lambda n: sphere_case(32, n), 8, 3, 9),          # partitions of 1280 vertices: split into tiles
+    (lambda n: strip_case(n), 3, 8, 16),              # boundary vertices, rings that run out
+    (lambda n: sphere_case(3, n), 2, 2, 5),           # tiny: rings cover the whole mesh
+    (lambda n: sphere_case(40, n), 16, 1, 3),         # ksteps = 1
+])
+def test_fused_tile_plan_f64(make, nparts, ksteps, steps):
+    """fused k-step kernel against the all-fp64 oracle (same arithmetic as the single-step plan)"""
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_F64)
+    plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+    plan.set_state(case.n0, case.c0)
+    plan.run(steps, case.dt, case.model)
+    n_gpu, c_gpu = plan.get_state()
+    n_ref, c_ref = case.ostats(ol.F64).step(case.n0, case.c0, case.dt, steps, case.model.as_array())
+    assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+
+
+def test_fused_tile_plan_f32_matches_single_step_plan():
+    """fp32: the fused kernel and the single-step kernel do the same arithmetic per row"""
+    case = sphere_case(64, 40)
+    case.mesh.init_stats(fa.PREC_F64)
+    n0, c0 = smooth_ic(case.pts)
+    fused = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=4)
+    single = fa.Plan(case.mesh, fa.PREC_F32)
+    outs = []
+    for plan in (fused, single):
+        plan.set_state(n0, c0)
+        plan.run(100, case.dt, case.model)
+        outs.append(plan.get_state())
+    assert rel_l2(outs[0][0], outs[1][0]) <= 1e-6 and rel_l2(outs[0][1], outs[1][1]) <= 1e-6
+    n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+    n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
+    assert rel_l2(outs[0][0], n_ref) <= TOL_F32 and rel_l2(outs[0][1], c_ref) <= TOL_F32
