@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--fuse", type=int, default=int(os.environ.get("FEM_FUSE_STEPS", "4")),
                     help="time steps fused per launch (0 = single-step sliced-ELL kernel)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = rehearsal only (ranks may share a GPU; halo staged through the host)")
     args = ap.parse_args()
 
     import torch
@@ -75,10 +77,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
+    local_dev = local_rank % torch.cuda.device_count() if args.dist_backend == "gloo" else local_rank
+    torch.cuda.set_device(local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+        else:
+            dist.init_process_group("gloo")
 
     wl = WORKLOADS[args.workload]
     t_host = time.perf_counter()
@@ -90,7 +96,7 @@ def main():
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     if world > 1:
         from fem_amd import dist as fdist
-        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision)
+        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse)
     else:
         from fem_amd import dist as fdist
         runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse)
@@ -115,7 +121,7 @@ def main():
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tmax[0]), float(tmax[1])
 
@@ -136,6 +142,7 @@ def main():
                                    % (args.workload, wl["nu"], V_total, 2 * V_total - 4, nparts),
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
+                       "halo_rings": getattr(runner, "krings", None),
                        "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": runner.measured_traffic(),

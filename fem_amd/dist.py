@@ -55,11 +55,12 @@ class _DevView:
 class HipShardStepper:
     """one rank's sharded plan on its GPU"""
 
-    def __init__(self, ordered, shard, precision, model, n_loc, c_loc):
+    def __init__(self, ordered, shard, precision, model, n_loc, c_loc, part=None, ksteps=0):
         import torch
         self.torch = torch
         self.shard = shard
-        self.plan = fa.Plan(ordered, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, model, shard=shard)
+        self.plan = fa.Plan(ordered, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, model, shard=shard,
+                            part=part, ksteps=ksteps)
         self.plan.set_state(n_loc, c_loc)
         self.dtype = torch.float32 if precision == "f32" else torch.float64
         self.typestr = "<f4" if precision == "f32" else "<f8"
@@ -107,9 +108,11 @@ def exchange_halo(stepper, shard, stream=None, group=None):
 class ShardedRun:
     """the mesh split along the partition ranges over `world` ranks; k ghost rings let every rank
     take k steps between two halo exchanges (communication-avoiding explicit stepping)"""
-    kernel_name = "sell_step_kernel"
-
-    def __init__(self, mesh, nparts, rank, world, precision="f32", seed=1, krings=None, make_stepper=None):
+    def __init__(self, mesh, nparts, rank, world, precision="f32", seed=1, krings=None, make_stepper=None,
+                 ksteps=0):
+        self.ksteps = ksteps
+        self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
+        self.steps_per_launch = max(1, ksteps)
         self.part = mesh.partition(nparts)
         om = self.part.ordered
         om.init_stats(fa.PREC_F64)
@@ -120,13 +123,22 @@ class ShardedRun:
         self.shard = fa.Shard(self.part, rank, world, self.krings)
         n0, c0 = fa.initial_condition(om.V, seed)                 # ordered numbering, identical on all ranks
         l2g = self.shard.loc2glob
-        make_stepper = make_stepper or HipShardStepper
-        self.stepper = make_stepper(om, self.shard, precision, self.model, n0[l2g], c0[l2g])
+        if make_stepper is None:
+            self.stepper = HipShardStepper(om, self.shard, precision, self.model, n0[l2g], c0[l2g], part=self.part,
+                                           ksteps=ksteps)
+        else:
+            self.stepper = make_stepper(om, self.shard, precision, self.model, n0[l2g], c0[l2g])
+        self.plan = getattr(self.stepper, "plan", None)
         self.V = om.V
         self.budget = self.krings                                  # ghosts are fresh: k steps allowed
+        # one exchange up front (re-sends the ghosts' own initial values): brings up the RCCL
+        # communicator and its buffers outside any timed region
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and world > 1:
+            exchange_halo(self.stepper, self.shard, None)
         self.vertices_per_launch = self.shard.n_local
         sb = 4 if precision == "f32" else 8
-        plan = getattr(self.stepper, "plan", None)
+        plan = self.plan
         self.layout_bytes_per_launch = (plan.operator_bytes() + 4 * sb * self.shard.n_local) if plan else None
 
     def run(self, nsteps, stream=None):

@@ -205,6 +205,7 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
  * magnitude of n itself; set/get_state convert in double.  fem_plan_run may be
  * given different constants later; the rewrite stays exact for any of them. */
 typedef struct fem_plan fem_plan;
+typedef struct fem_shard fem_shard;   /* section 5 */
 int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out);
 /* Same operator in the fused-tile layout: every workgroup stages one partition (+ ksteps rings
  * of neighbours) in LDS, keeps its operator rows in registers and takes up to `ksteps` time
@@ -213,7 +214,7 @@ int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *mod
  * FEM_ERR_LIMIT on meshes with a vertex of valence > 6 (use fem_plan_create there).
  * fem_plan_run on such a plan issues ceil(nsteps / ksteps) launches. */
 int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts,
-                          const struct fem_shard *shard, int precision, const fem_model *model,
+                          const fem_shard *shard, int precision, const fem_model *model,
                           int ksteps, fem_plan **out);
 /* geometry of a tiled plan: fused steps, tile count, largest tile (rows staged in LDS), operator
  * rows loaded per launch (sum over tiles), workgroup size and rows per thread; ksteps = 0 for a
@@ -245,7 +246,6 @@ uint64_t fem_plan_operator_bytes(const fem_plan *p);
  * ghost copies of all vertices within `krings` edges of it.  Local numbering:
  * owned vertices (ascending), then ghosts (ascending global id, hence grouped
  * by owner rank).  With k rings a rank takes k steps between halo exchanges. */
-typedef struct fem_shard fem_shard;
 int fem_shard_create(const fem_mesh *ordered, int n, const fem_uint *node_parts, int rank,
                      int nranks, int krings, fem_shard **out);
 void fem_shard_destroy(fem_shard *s);

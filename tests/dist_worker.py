@@ -15,6 +15,7 @@ ap.add_argument("--nparts", type=int, default=8)
 ap.add_argument("--krings", type=int, default=2)
 ap.add_argument("--steps", type=int, default=7)
 ap.add_argument("--precision", default="f64")
+ap.add_argument("--fuse", type=int, default=0)
 ap.add_argument("--out", required=True)
 a = ap.parse_args()
 
@@ -35,7 +36,8 @@ else:
     torch.cuda.set_device(0)                      # all ranks share the one GPU of the test box
     stream = torch.cuda.current_stream()
 pts, tri = fa.make_icosphere(a.sphere, 0.1)
-run = ShardedRun(fa.Mesh(pts, tri), a.nparts, rank, world, a.precision, seed=3, krings=a.krings, make_stepper=make)
+run = ShardedRun(fa.Mesh(pts, tri), a.nparts, rank, world, a.precision, seed=3, krings=a.krings, make_stepper=make,
+                 ksteps=a.fuse)
 # split the run so that exchanges fall both inside and between run() calls
 run.run(a.steps // 2, stream)
 run.run(a.steps - a.steps // 2, stream)

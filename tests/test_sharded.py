@@ -87,8 +87,9 @@ def test_shard_lists_are_consistent():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,krings,precision", [(4, 1, "f64"), (4, 3, "f64"), (3, 8, "f32")])
-def test_gpu_shards_loopback(world, krings, precision):
+@pytest.mark.parametrize("world,krings,precision,ksteps", [(4, 1, "f64", 0), (4, 3, "f64", 0), (3, 8, "f32", 0),
+                                                           (4, 4, "f64", 2), (3, 8, "f64", 4), (2, 8, "f32", 4)])
+def test_gpu_shards_loopback(world, krings, precision, ksteps):
     """several shards on one card, exchanged in-process: HIP shard plans + pack kernel"""
     import torch
     from fem_amd.dist import HipShardStepper
@@ -100,9 +101,12 @@ def test_gpu_shards_loopback(world, krings, precision):
     model = fa.default_model()
     n0, c0 = fa.initial_condition(om.V, 3)
     shards = [fa.Shard(part, r, world, krings) for r in range(world)]
-    steppers = [HipShardStepper(om, s, precision, model, n0[s.loc2glob], c0[s.loc2glob]) for s in shards]
+    steppers = [HipShardStepper(om, s, precision, model, n0[s.loc2glob], c0[s.loc2glob], part=part, ksteps=ksteps)
+                for s in shards]
     budget = krings
-    for _ in range(steps):
+    chunk = max(1, ksteps)
+    assert krings % chunk == 0 and steps % chunk == 0
+    for _ in range(steps // chunk):
         if budget == 0:
             sends = [st.pack(None).clone() for st in steppers]
             torch.cuda.synchronize()
@@ -115,8 +119,8 @@ def test_gpu_shards_loopback(world, krings, precision):
                     pos += cnt
             budget = krings
         for st in steppers:
-            st.step(1, dt, model, None)
-        budget -= 1
+            st.step(chunk, dt, model, None)
+        budget -= chunk
     tol = 1e-11 if precision == "f64" else 1e-5
     for s, st in zip(shards, steppers):
         n, c = st.get_owned()
@@ -128,7 +132,7 @@ def test_gpu_two_ranks_gloo(tmp_path):
     """ShardedRun with the HIP stepper as 2 processes sharing the card (exchange staged via gloo)"""
     nu, nparts, steps = 16, 12, 11
     part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
-    res = launch(2, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=4, steps=steps, precision="f64")
+    res = launch(2, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=4, steps=steps, precision="f64", fuse=2)
     for r in res:
         b, e = int(r["own_begin"]), int(r["own_end"])
         assert rel_l2(r["n"], n_ref[b:e]) <= 1e-11 and rel_l2(r["c"], c_ref[b:e]) <= 1e-11
