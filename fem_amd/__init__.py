@@ -57,6 +57,8 @@ lib.fem_plan_operator_bytes.restype = C.c_uint64
 lib.fem_plan_operator_bytes.argtypes = [vp]
 lib.fem_free.argtypes = [vp]
 lib.fem_plan_pack_halo.argtypes = [vp, C.c_uint64, vp]
+lib.fem_plan_coef_count.restype = C.c_uint64
+lib.fem_plan_coef_count.argtypes = [vp]
 for _name in ("fem_mesh_destroy", "fem_ref_layout_destroy", "fem_ref_device_destroy", "fem_plan_destroy",
               "fem_shard_destroy"):
     getattr(lib, _name).argtypes = [vp]
@@ -357,13 +359,21 @@ class Shard:
 class Plan:
     """Native plan: sliced-ELL operator + ping-pong state on the device."""
 
-    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None, part=None, ksteps=0):
+    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None, part=None, ksteps=0, assemble=False):
         """ksteps > 0 (with part = the Partition of `ordered`): fused-tile layout, up to ksteps time
-        steps per launch; otherwise the sliced-ELL layout, one step per launch"""
+        steps per launch; otherwise the sliced-ELL layout, one step per launch.
+        assemble=True keeps connectivity/positions on the device for fem_plan_assemble."""
         h = vp()
         mp = C.byref(model) if model is not None else None
         self.ksteps = ksteps
-        if ksteps > 0:
+        self.F = ordered.F
+        if assemble:
+            _check(lib.fem_plan_create_ex(ordered.h, C.c_int(part.n if part is not None else 0),
+                                          _ptr(part.node_parts, u32p) if part is not None else None,
+                                          shard.h if shard is not None else None, C.c_int(precision), mp,
+                                          C.c_int(ksteps), C.c_uint(1), C.byref(h)))
+            self.V = shard.n_local if shard is not None else ordered.V
+        elif ksteps > 0:
             _check(lib.fem_plan_create_tiled(ordered.h, C.c_int(part.n), _ptr(part.node_parts, u32p),
                                              shard.h if shard is not None else None, C.c_int(precision), mp,
                                              C.c_int(ksteps), C.byref(h)))
@@ -375,6 +385,32 @@ class Plan:
             _check(lib.fem_plan_create_shard(ordered.h, shard.h, C.c_int(precision), mp, C.byref(h)))
             self.V = shard.n_local
         self.h, self.precision = h, precision
+
+    def set_points(self, points):
+        pts = np.ascontiguousarray(points, np.float64)
+        _check(lib.fem_plan_set_points(self.h, _ptr(pts, f64p)))
+
+    def deform(self, amplitude, wavenumber, phase, stream=None):
+        _check(lib.fem_plan_deform(self.h, C.c_double(amplitude), C.c_double(wavenumber), C.c_double(phase),
+                                   vp(stream or 0)))
+
+    def assemble(self, stream=None):
+        _check(lib.fem_plan_assemble(self.h, vp(stream or 0)))
+
+    def max_edge(self):
+        v = C.c_double()
+        _check(lib.fem_plan_max_edge(self.h, C.byref(v)))
+        return v.value
+
+    def face_records(self):
+        out = np.empty((self.F, 16))
+        _check(lib.fem_plan_face_records(self.h, _ptr(out, f64p)))
+        return out
+
+    def coef(self):
+        out = np.empty(lib.fem_plan_coef_count(self.h))
+        _check(lib.fem_plan_download_coef(self.h, _ptr(out, f64p)))
+        return out.reshape(-1, 4)
 
     def tile_info(self):
         k, thr, rpt = C.c_int(), C.c_int(), C.c_int()

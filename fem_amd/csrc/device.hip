@@ -296,6 +296,163 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   for (uint i = t; i < n0; i += TPB) dst[base + i] = cur[i];
 }
 
+
+// ---------------------------------------------------------------------------
+// Device assembly (initMeshStats on the GPU; reference src/mesh_function.cpp:70-397).
+//   assemble_faces_kernel : one thread per element.  Coalesced SoA connectivity loads, three
+//     position gathers (16-B records), then everything the reference derives per face/half-edge:
+//     corner angles + cotangents (A1, :70-160), area (A2, :162-216), longest edge (A4, :310-350),
+//     hat-function gradients gradVec12/13 (A5, :351-397).  One 64-B record per face:
+//     {ang_a, ang_b, ang_c, area | cot_a, cot_b, cot_c, maxEdge | g12.xyz, 0 | g13.xyz, 0}.
+//   assemble_rows_*_kernel : one thread per operator row; the row's entries name the faces left
+//     and right of each edge (pack.cpp), so the lumped mass (sum of area/3), the angle sum and
+//     the per-edge cotangent sums (A3, :219-271) are per-row sequential reductions over those
+//     records -- a segmented reduction with the segments fixed by the layout: no atomics,
+//     bit-reproducible.  Writes (w, Cx, Cy, Cz) straight into the plan's operator array.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T dev_acos(T x);
+template <> __device__ __forceinline__ float dev_acos<float>(float x) { return acosf(x); }
+template <> __device__ __forceinline__ double dev_acos<double>(double x) { return acos(x); }
+template <typename T> __device__ __forceinline__ T dev_tan(T x);
+template <> __device__ __forceinline__ float dev_tan<float>(float x) { return tanf(x); }
+template <> __device__ __forceinline__ double dev_tan<double>(double x) { return tan(x); }
+template <typename T> __device__ __forceinline__ T dev_sqrt(T x);
+template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
+
+template <typename T>
+__device__ __forceinline__ void corner_angle(const T *p1, const T *p2, const T *p3, T &ang, T &cot) {
+  // angle at p2 between p1 and p3; precedence of mesh_function.cpp:126: dot(v21, v23 / (|v21| |v23|))
+  T v21[3], v23[3], n21 = 0, n23 = 0, d = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { v21[k] = p1[k] - p2[k]; v23[k] = p3[k] - p2[k]; n21 += v21[k] * v21[k]; n23 += v23[k] * v23[k]; }
+  const T sden = dev_sqrt(n21) * dev_sqrt(n23);
+#pragma unroll
+  for (int k = 0; k < 3; k++) d += v21[k] * (v23[k] / sden);
+  ang = dev_acos(d);
+  cot = (T)1 / dev_tan(ang);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_faces_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                             const uint *__restrict__ tri0, const uint *__restrict__ tri1,
+                                                             const uint *__restrict__ tri2, typename Vec<T>::t4 *__restrict__ rec,
+                                                             uint F, unsigned long long *__restrict__ maxEdgeBits) {
+  typedef typename Vec<T>::t4 T4;
+  const uint f = blockIdx.x * blockDim.x + threadIdx.x;
+  T me = 0;
+  if (f < F) {
+    const T4 A = pos[tri0[f]], B = pos[tri1[f]], C = pos[tri2[f]];
+    const T a[3] = {A.x, A.y, A.z}, b[3] = {B.x, B.y, B.z}, c[3] = {C.x, C.y, C.z};
+    T4 r0, r1, r2, r3;
+    corner_angle<T>(c, a, b, r0.x, r1.x);               // half-edge c->a ends at a
+    corner_angle<T>(a, b, c, r0.y, r1.y);
+    corner_angle<T>(b, c, a, r0.z, r1.z);
+    // area = |(p1-p2) x (p3-p2)| / 2 with (p1,p2,p3) = (c,a,b)
+    T u[3], v[3], e1[3], e2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { u[k] = c[k] - a[k]; v[k] = b[k] - a[k]; e1[k] = c[k] - b[k]; e2[k] = a[k] - b[k]; }
+    const T cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+    const T area = dev_sqrt(cx * cx + cy * cy + cz * cz) / 2;
+    r0.w = area;
+    T nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const T nl = dev_sqrt(nx * nx + ny * ny + nz * nz);
+    if (nl != 0) { nx /= nl; ny /= nl; nz /= nl; } else { nx = ny = nz = 0; }
+    const T twoA = 2 * area;
+    // gradVec12 = N x (pt1 - pt3) / 2A, (pt1, pt3) = (c, b);  gradVec13 = N x (pt2 - pt1) / 2A = N x (a - c) / 2A
+    r2.x = (ny * e1[2] - nz * e1[1]) / twoA; r2.y = (nz * e1[0] - nx * e1[2]) / twoA; r2.z = (nx * e1[1] - ny * e1[0]) / twoA; r2.w = 0;
+    r3.x = (ny * (-u[2]) - nz * (-u[1])) / twoA; r3.y = (nz * (-u[0]) - nx * (-u[2])) / twoA; r3.z = (nx * (-u[1]) - ny * (-u[0])) / twoA; r3.w = 0;
+    const T lab = dev_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const T lbc = dev_sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    const T lca = dev_sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    me = fmax(lab, fmax(lbc, lca));
+    r1.w = me;
+    rec[4 * (size_t)f] = r0; rec[4 * (size_t)f + 1] = r1; rec[4 * (size_t)f + 2] = r2; rec[4 * (size_t)f + 3] = r3;
+  }
+  // A4: longest edge -> one atomic per wave (positive doubles order like their bit patterns)
+  double m = (double)me;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxEdgeBits, (unsigned long long)__double_as_longlong(m));
+}
+
+template <typename T> __device__ __forceinline__ T comp(const typename Vec<T>::t4 &v, uint k) {
+  return k == 0 ? v.x : (k == 1 ? v.y : v.z);
+}
+
+// one operator row: entries e(k) = first + k * stride, k < width
+template <typename T>
+__device__ __forceinline__ void assemble_row(const typename Vec<T>::t4 *__restrict__ rec, const uint *__restrict__ topo,
+                                             typename Vec<T>::t4 *__restrict__ coef, size_t first, size_t stride, uint width) {
+  typedef typename Vec<T>::t4 T4;
+  T area3 = 0, theta = 0;
+  for (uint k = 0; k < width; k++) {
+    const uint t1 = topo[2 * (first + k * stride)];
+    if (t1 != 0xffffffffu) {
+      const T4 r0 = rec[4 * (size_t)(t1 >> 2)];
+      theta += comp<T>(r0, t1 & 3u);
+      area3 += r0.w / 3;
+    }
+  }
+  for (uint k = 0; k < width; k++) {
+    const size_t e = first + k * stride;
+    const uint t1 = topo[2 * e], t2 = topo[2 * e + 1];
+    T w = 0, cx = 0, cy = 0, cz = 0;
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const uint t = side == 0 ? t1 : t2;
+      if (t == 0xffffffffu) continue;
+      const size_t f = t >> 2;
+      const uint cv = t & 3u;
+      const uint cj = side == 0 ? (cv + 1) % 3 : (cv + 2) % 3;       // corner of the neighbour j
+      const uint co = 3 - cv - cj;                                    // corner opposite the edge (v, j)
+      const T4 r0 = rec[4 * f], r1 = rec[4 * f + 1], g12 = rec[4 * f + 2], g13 = rec[4 * f + 3];
+      w += comp<T>(r1, co);
+      const T a = comp<T>(r0, cv);
+      const T gx = cj == 0 ? g12.x : (cj == 1 ? g13.x : -(g12.x + g13.x));
+      const T gy = cj == 0 ? g12.y : (cj == 1 ? g13.y : -(g12.y + g13.y));
+      const T gz = cj == 0 ? g12.z : (cj == 1 ? g13.z : -(g12.z + g13.z));
+      cx += a * gx; cy += a * gy; cz += a * gz;
+    }
+    T4 o;
+    o.x = area3 > 0 ? w / (2 * area3) : (T)0;
+    if (theta > 0) { o.y = cx / theta; o.z = cy / theta; o.w = cz / theta; } else { o.y = o.z = o.w = 0; }
+    if (t1 == 0xffffffffu && t2 == 0xffffffffu) { o.x = o.y = o.z = o.w = 0; }
+    coef[e] = o;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ rec,
+                                                                 const uint *__restrict__ topo, const uint *__restrict__ slice_off,
+                                                                 typename Vec<T>::t4 *__restrict__ coef, uint nslices) {
+  const uint slice = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  if (slice >= nslices) return;
+  const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
+  assemble_row<T>(rec, topo, coef, (size_t)off + lane, 64, width);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ rec,
+                                                                 const uint *__restrict__ topo, const uint *__restrict__ meta,
+                                                                 typename Vec<T>::t4 *__restrict__ coef, uint W) {
+  const uint *mt = meta + 16 * (size_t)blockIdx.x;
+  const uint roff = mt[2], rpad = mt[3], rows = mt[5 + mt[4] - 1];
+  for (uint r = threadIdx.x; r < rows; r += blockDim.x) assemble_row<T>(rec, topo, coef, (size_t)roff + r, rpad, W);
+}
+
+// seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
+template <typename T>
+__global__ __launch_bounds__(256) void deform_kernel(const typename Vec<T>::t4 *__restrict__ base,
+                                                     typename Vec<T>::t4 *__restrict__ pos, uint V, T amp, T q, T phase) {
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V) return;
+  typename Vec<T>::t4 p = base[i];
+  const T s = (T)1 + amp * sin(q * p.x + phase) * cos(q * p.y - (T)0.5 * phase) * sin(q * p.z + (T)0.25 * phase);
+  p.x *= s; p.y *= s; p.z *= s;
+  pos[i] = p;
+}
+
 // halo pack: dst[i] = state[send_idx[i]] (8 or 16 B per lane, coalesced stores)
 template <typename T2>
 __global__ __launch_bounds__(256) void pack_halo_kernel(const T2 *__restrict__ state, const uint *__restrict__ send_idx,
@@ -356,11 +513,45 @@ struct fem_plan {
   uint64_t tile_bytes = 0;
   DevBuf<fem_uint> tmeta, tghost, tidx2;
   void *tcoef = nullptr;
+  // device assembly (FEM_PLAN_DEVICE_ASSEMBLY): connectivity SoA, positions, per-face records, entry tables
+  bool can_assemble = false;
+  fem_uint F = 0, Vg = 0;
+  DevBuf<fem_uint> tri0, tri1, tri2, topo;
+  void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
+  unsigned long long *maxedge = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
   void *state[2] = {nullptr, nullptr};   // deviations from (base_n, base_c), interleaved
   int cur = 0;
   double base_n = 1.0, base_c = 0.5;
 };
+
+template <typename T> static int setPoints(fem_plan *p, const double *pts) {
+  std::vector<T> h(4 * (size_t)p->Vg);
+  for (size_t i = 0; i < p->Vg; i++) { h[4 * i] = (T)pts[3 * i]; h[4 * i + 1] = (T)pts[3 * i + 1]; h[4 * i + 2] = (T)pts[3 * i + 2]; h[4 * i + 3] = 0; }
+  HIP_TRY(hipMemcpy(p->pos0, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->pos, p->pos0, sizeof(T) * h.size(), hipMemcpyDeviceToDevice));
+  return FEM_OK;
+}
+
+template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
+  typedef typename Vec<T>::t4 T4;
+  hipLaunchKernelGGL(assemble_faces_kernel<T>, dim3((p->F + 255) / 256), dim3(256), 0, st, (const T4 *)p->pos, p->tri0.p,
+                     p->tri1.p, p->tri2.p, (T4 *)p->rec, p->F, p->maxedge);
+  if (p->ksteps > 0)
+    hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(p->ntiles), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
+                       p->tmeta.p, (T4 *)p->tcoef, (fem_uint)kTileW);
+  else
+    hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(p->nblocks), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
+                       p->slice_off.p, (T4 *)p->coef, p->nslices);
+}
+
+template <typename T> static int downloadAs(const void *dev, size_t count, double *out) {
+  std::vector<T> h(count);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(h.data(), dev, sizeof(T) * count, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < count; i++) out[i] = (double)h[i];
+  return FEM_OK;
+}
 
 template <typename T, int C>
 static hipError_t launchTile(fem_plan *p, const void *src, void *dst, int nsteps, const ModelT<T> &m, hipStream_t stream) {
@@ -531,6 +722,8 @@ void fem_plan_destroy(fem_plan *p) {
   if (!p) return;
   p->slice_off.release(); p->idx.release(); p->send_idx.release();
   p->tmeta.release(); p->tghost.release(); p->tidx2.release();
+  p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release();
+  for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
@@ -538,7 +731,7 @@ void fem_plan_destroy(fem_plan *p) {
 }
 
 static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int precision, const fem_model *model,
-                      int ksteps, int n, const fem_uint *node_parts, fem_plan **out) {
+                      int ksteps, int n, const fem_uint *node_parts, unsigned flags, fem_plan **out) {
   if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64) || ksteps < 0 || ksteps > 8)
     return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
   if (ksteps > 0 && (!node_parts || n < 1)) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partition ranges missing");
@@ -602,6 +795,17 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     uploadCoef(&p->coef, L.coef);
   }
   ok(hipMalloc(&p->state[0], 2 * sb * p->V)) && ok(hipMalloc(&p->state[1], 2 * sb * p->V));
+  if (e == hipSuccess && (flags & FEM_PLAN_DEVICE_ASSEMBLY)) {
+    const fem::SimpleTriMesh &m = ordered->mesh;
+    p->F = m.n_faces(); p->Vg = m.n_vertices(); p->can_assemble = true;
+    std::vector<fem_uint> t0(p->F), t1(p->F), t2(p->F);
+    for (fem_uint f = 0; f < p->F; f++) { t0[f] = m.faces[3 * (size_t)f]; t1[f] = m.faces[3 * (size_t)f + 1]; t2[f] = m.faces[3 * (size_t)f + 2]; }
+    const std::vector<fem_uint> &topo = ksteps > 0 ? TL.topo : L.topo;
+    ok(p->tri0.alloc(p->F)) && ok(p->tri0.upload(t0.data())) && ok(p->tri1.alloc(p->F)) && ok(p->tri1.upload(t1.data())) &&
+    ok(p->tri2.alloc(p->F)) && ok(p->tri2.upload(t2.data())) && ok(p->topo.alloc(topo.size())) && ok(p->topo.upload(topo.data())) &&
+    ok(hipMalloc(&p->pos, 4 * sb * p->Vg)) && ok(hipMalloc(&p->pos0, 4 * sb * p->Vg)) &&
+    ok(hipMalloc(&p->rec, 16 * sb * (p->F ? p->F : 1))) && ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8));
+  }
   if (e == hipSuccess && shard)
     ok(p->send_idx.alloc(shard->send_idx.size())) && (shard->send_idx.empty() || ok(p->send_idx.upload(shard->send_idx.data())));
   if (e == hipSuccess) {
@@ -614,19 +818,29 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
 }
 
 int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out) {
-  return planCreate(ordered, nullptr, precision, model, 0, 0, nullptr, out);
+  return planCreate(ordered, nullptr, precision, model, 0, 0, nullptr, 0, out);
+}
+
+int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts, const fem_shard *shard,
+                       int precision, const fem_model *model, int ksteps, unsigned flags, fem_plan **out) {
+  int rc = planCreate(ordered, shard ? &shard->s : nullptr, precision, model, ksteps, n, node_parts, flags, out);
+  if (rc == FEM_OK && (flags & FEM_PLAN_DEVICE_ASSEMBLY)) {
+    rc = fem_plan_set_points(*out, ordered->mesh.points.data());
+    if (rc != FEM_OK) { fem_plan_destroy(*out); *out = nullptr; }
+  }
+  return rc;
 }
 
 int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts, const fem_shard *shard,
                           int precision, const fem_model *model, int ksteps, fem_plan **out) {
   if (ksteps < 1) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: ksteps must be 1..8");
-  return planCreate(ordered, shard ? &shard->s : nullptr, precision, model, ksteps, n, node_parts, out);
+  return planCreate(ordered, shard ? &shard->s : nullptr, precision, model, ksteps, n, node_parts, 0, out);
 }
 
 int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int precision, const fem_model *model,
                           fem_plan **out) {
   if (!shard) return fail(FEM_ERR_INVALID, "fem_plan_create_shard: null shard");
-  return planCreate(ordered, &shard->s, precision, model, 0, 0, nullptr, out);
+  return planCreate(ordered, &shard->s, precision, model, 0, 0, nullptr, 0, out);
 }
 
 int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream) {
@@ -725,6 +939,61 @@ int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, i
   if (n_vertices) *n_vertices = p->V;
   if (scalar_bytes) *scalar_bytes = p->precision == FEM_PREC_F32 ? 4 : 8;
   return FEM_OK;
+}
+
+
+// ---- device assembly -----------------------------------------------------------------------------
+
+int fem_plan_set_points(fem_plan *p, const double *points) {
+  if (!p || !points || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_set_points: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
+  return p->precision == FEM_PREC_F32 ? setPoints<float>(p, points) : setPoints<double>(p, points);
+}
+
+int fem_plan_assemble(fem_plan *p, void *stream) {
+  if (!p || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_assemble: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
+  HIP_TRY(hipMemsetAsync(p->maxedge, 0, 8, (hipStream_t)stream));
+  if (p->precision == FEM_PREC_F32) launchAssemble<float>(p, (hipStream_t)stream);
+  else launchAssemble<double>(p, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+int fem_plan_deform(fem_plan *p, double amplitude, double wavenumber, double phase, void *stream) {
+  if (!p || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_deform: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
+  const dim3 grid((p->Vg + 255) / 256);
+  if (p->precision == FEM_PREC_F32)
+    hipLaunchKernelGGL(deform_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos0, (float4 *)p->pos,
+                       p->Vg, (float)amplitude, (float)wavenumber, (float)phase);
+  else
+    hipLaunchKernelGGL(deform_kernel<double>, grid, dim3(256), 0, (hipStream_t)stream, (const double4 *)p->pos0, (double4 *)p->pos,
+                       p->Vg, amplitude, wavenumber, phase);
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+int fem_plan_max_edge(fem_plan *p, double *maxEdgeLen) {
+  if (!p || !p->can_assemble || !maxEdgeLen) return fail(FEM_ERR_INVALID, "fem_plan_max_edge: bad argument");
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(maxEdgeLen, p->maxedge, 8, hipMemcpyDeviceToHost));
+  return FEM_OK;
+}
+
+int fem_plan_face_records(fem_plan *p, double *rec16F) {
+  if (!p || !p->can_assemble || !rec16F) return fail(FEM_ERR_INVALID, "fem_plan_face_records: bad argument");
+  return p->precision == FEM_PREC_F32 ? downloadAs<float>(p->rec, 16 * (size_t)p->F, rec16F)
+                                      : downloadAs<double>(p->rec, 16 * (size_t)p->F, rec16F);
+}
+
+uint64_t fem_plan_coef_count(const fem_plan *p) {
+  if (!p) return 0;
+  return p->ksteps > 0 ? (uint64_t)p->tidx2.n * 2 * 4 : (uint64_t)p->entries * 4;
+}
+
+int fem_plan_download_coef(fem_plan *p, double *out) {
+  if (!p || !out) return fail(FEM_ERR_INVALID, "fem_plan_download_coef: null");
+  const void *dev = p->ksteps > 0 ? p->tcoef : p->coef;
+  const size_t n = fem_plan_coef_count(p);
+  return p->precision == FEM_PREC_F32 ? downloadAs<float>(dev, n, out) : downloadAs<double>(dev, n, out);
 }
 
 int fem_plan_tile_info(const fem_plan *p, int *ksteps, fem_uint *ntiles, fem_uint *max_local, uint64_t *rows_loaded,

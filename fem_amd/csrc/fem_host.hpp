@@ -120,11 +120,13 @@ struct SellLayout {
   std::vector<uint> slice_off;               // [nslices+1] entry offsets (multiples of 64)
   std::vector<uint> idx;                     // [entries]
   std::vector<double> coef;                  // [4*entries] (w, Cx, Cy, Cz)
+  std::vector<uint> topo;                    // [2*entries] (f1, f2) of RowOp, for device assembly
 };
 // Folded operator in CSR form over local rows (whole mesh, or a shard's loc2glob list).
 struct RowOp {
   uint V = 0;
   std::vector<uint> rowptr, col;             // [V+1], [nnz] local column ids, ascending global order
+  std::vector<uint> f1, f2;                  // [nnz] face left of v->j / of j->v, as (face << 2 | corner of v), ~0 = none
   std::vector<double> coef;                  // [4*nnz] (w, Cx, Cy, Cz)
 };
 int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &out, const uint *loc2glob = nullptr,
@@ -140,6 +142,7 @@ struct TileLayout {
   std::vector<uint> ghost;                   // row ids of the ring rows of every tile
   std::vector<uint> idx2;                    // packed 16-bit local column ids
   std::vector<double> coef;                  // [4*entries]
+  std::vector<uint> topo;                    // [2*entries] (f1, f2) of RowOp, for device assembly
 };
 int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ranges, int ksteps, uint T, uint R,
                    uint W, uint maxLocal, TileLayout &out);

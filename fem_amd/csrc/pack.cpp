@@ -119,6 +119,7 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
   for (uint r = 0; r < V; r++) { const uint v = loc2glob ? loc2glob[r] : r; nnzMax += m.rowptr[v + 1] - m.rowptr[v]; }
   if (nnzMax > 0xffffffffull) return FEM_ERR_LIMIT;
   o.col.reserve(nnzMax);
+  o.f1.reserve(nnzMax); o.f2.reserve(nnzMax);
   o.coef.reserve(4 * nnzMax);
 
   auto hatGrad = [&](int f, int corner, double *g) {   // corner 0 (a): gradVec12, 1 (b): gradVec13, 2 (c): -(both)
@@ -158,6 +159,9 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
         for (int d = 0; d < 3; d++) C[d] /= theta;
       }
       o.col.push_back(lc);
+      // faces on the two sides of edge (v, j) with v's corner in each (face << 2 | corner)
+      o.f1.push_back(h < H3 ? ((uint)(h / 3) << 2) | (uint)(h % 3) : 0xffffffffu);
+      o.f2.push_back(ho < H3 ? ((uint)(ho / 3) << 2) | (uint)((ho % 3 + 1) % 3) : 0xffffffffu);
       o.coef.push_back(s.wHej[h]);
       o.coef.push_back(C[0]); o.coef.push_back(C[1]); o.coef.push_back(C[2]);
     }
@@ -184,6 +188,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
   const size_t entries = o.slice_off[o.nslices];
   o.idx.resize(entries);
   o.coef.assign(4 * entries, 0.0);
+  o.topo.assign(2 * entries, 0xffffffffu);
   for (uint sl = 0; sl < o.nslices; sl++) {
     const uint off = o.slice_off[sl], width = (o.slice_off[sl + 1] - off) / 64;
     for (uint lane = 0; lane < 64; lane++) {
@@ -195,6 +200,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
       for (uint e = op.rowptr[row]; e < op.rowptr[row + 1]; e++, k++) {
         const size_t pos = off + (size_t)k * 64 + lane;
         o.idx[pos] = op.col[e];
+        o.topo[2 * pos] = op.f1[e]; o.topo[2 * pos + 1] = op.f2[e];
         for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)e + d];
       }
     }
@@ -273,6 +279,7 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
     o.meta.insert(o.meta.end(), meta, meta + 16);
     o.ghost.insert(o.ghost.end(), local.begin() + m[0], local.end());
     o.coef.resize(4 * (rowOff + (size_t)W * rowsPad), 0.0);
+    o.topo.resize(2 * (rowOff + (size_t)W * rowsPad), 0xffffffffu);
     o.idx2.resize((rowOff + (size_t)W * rowsPad) / 2, 0u);
     for (uint r = 0; r < rowsPad; r++) {
       uint ids[16];
@@ -282,7 +289,9 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
         uint w = 0;
         for (uint q = op.rowptr[v]; q < op.rowptr[v + 1]; q++, w++) {
           ids[w] = locId[op.col[q]];
-          for (int d = 0; d < 4; d++) o.coef[4 * (rowOff + (size_t)w * rowsPad + r) + d] = op.coef[4 * (size_t)q + d];
+          const size_t pos = rowOff + (size_t)w * rowsPad + r;
+          o.topo[2 * pos] = op.f1[q]; o.topo[2 * pos + 1] = op.f2[q];
+          for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)q + d];
         }
       }
       for (uint w = 0; w < W; w += 2) o.idx2[rowOff / 2 + (size_t)(w / 2) * rowsPad + r] = ids[w] | (ids[w + 1] << 16);

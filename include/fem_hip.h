@@ -216,6 +216,35 @@ int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *mod
 int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                           const fem_shard *shard, int precision, const fem_model *model,
                           int ksteps, fem_plan **out);
+/* General form of the three creators above.  flags: FEM_PLAN_DEVICE_ASSEMBLY keeps the mesh
+ * connectivity, vertex positions and per-entry face tables on the device so that the operator can
+ * be re-assembled there (fem_plan_assemble) -- initMeshStats on the GPU, mesh_function.cpp:27-67.
+ * ksteps = 0: sliced-ELL layout; n/node_parts may then be 0/NULL. */
+#define FEM_PLAN_DEVICE_ASSEMBLY 1u
+int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts,
+                       const fem_shard *shard, int precision, const fem_model *model, int ksteps,
+                       unsigned flags, fem_plan **out);
+/* vertex positions of the ordered mesh (3 doubles per vertex): new base positions + current positions */
+int fem_plan_set_points(fem_plan *p, const double *points);
+/* current positions = base positions scaled radially by 1 + amplitude * sin(q x + phase) cos(q y - phase/2)
+ * sin(q z + phase/4) (q = wavenumber): the seeded smooth deformation of BASELINE config 5 */
+int fem_plan_deform(fem_plan *p, double amplitude, double wavenumber, double phase, void *stream);
+/* Device assembly from the current positions, two kernels, async on `stream`:
+ * per element: corner angles + cotangents (computeAngles, mesh_function.cpp:70-160), area
+ * (computeAreas, :162-216), longest edge (computeMaxEdgeLength, :310-350), gradVec12/13
+ * (computeGradVectors, :351-397); per operator row: lumped mass, cot-Laplacian weights
+ * (computeLaplacianWeights, :219-271) and the folded vertex-gradient coefficients, written into the
+ * plan's operator array.  Arithmetic type = the plan's precision (FEM_PREC_F32 ~ the reference's
+ * Vec3f geometry). */
+int fem_plan_assemble(fem_plan *p, void *stream);
+/* maxEdgeLen of the last fem_plan_assemble (dt = 0.1 maxEdgeLen^2, main.cpp:188); synchronises */
+int fem_plan_max_edge(fem_plan *p, double *maxEdgeLen);
+/* per-face records of the last assembly, 16 doubles per face:
+ * {ang_a, ang_b, ang_c, area, cot_a, cot_b, cot_c, maxEdge, g12.x, g12.y, g12.z, 0, g13.x, g13.y, g13.z, 0} */
+int fem_plan_face_records(fem_plan *p, double *rec16F);
+/* the plan's operator array (4 values per entry, layout order), for comparing host- and device-assembled operators */
+uint64_t fem_plan_coef_count(const fem_plan *p);
+int fem_plan_download_coef(fem_plan *p, double *out);
 /* geometry of a tiled plan: fused steps, tile count, largest tile (rows staged in LDS), operator
  * rows loaded per launch (sum over tiles), workgroup size and rows per thread; ksteps = 0 for a
  * sliced-ELL plan.  Any out-pointer may be NULL. */

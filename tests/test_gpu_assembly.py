@@ -1,0 +1,84 @@
+"""Device assembly (initMeshStats on the GPU, reference src/mesh_function.cpp:27-397) against the
+CPU oracle: per-face records (A1, A2, A4, A5) and the assembled operator (A3 + folded gradients),
+then time steps on a device-assembled, deformed mesh.
+Bars: fp64 plan <= 1e-11 relative; fp32 plan (the reference's Vec3f geometry) <= 2e-5 relative
+against the mixed-precision oracle -- the reference's own float geometry has that round-off."""
+import numpy as np
+import pytest
+
+import fem_amd as fa
+import oracle_lib as ol
+from helpers import Case, rel_l2, sphere_case, strip_case
+
+pytestmark = pytest.mark.gpu
+
+
+def check_records(rec, st, F, tol):
+    he = st.meshAngle[:3 * F].reshape(F, 3)          # half-edge 3f+k ends at corner (k+1)%3
+    cot = st.meshCot[:3 * F].reshape(F, 3)
+    assert np.abs(rec[:, 0:3] - he[:, [2, 0, 1]]).max() <= tol * np.pi
+    assert np.abs(rec[:, 4:7] - cot[:, [2, 0, 1]]).max() <= 50 * tol * np.abs(cot).max()
+    assert np.abs(rec[:, 3] - st.meshArea).max() <= tol * st.meshArea.max()
+    g12, g13 = np.asarray(st.gradVec12, np.float64), np.asarray(st.gradVec13, np.float64)
+    assert np.abs(rec[:, 8:11] - g12).max() <= tol * np.abs(g12).max()
+    assert np.abs(rec[:, 12:15] - g13).max() <= tol * np.abs(g13).max()
+    assert abs(rec[:, 7].max() - st.maxEdgeLen) <= tol * st.maxEdgeLen
+
+
+@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(12, n), 6), (lambda n: strip_case(n), 3)])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("ksteps", [0, 4])
+def test_device_assembly_matches_oracle(make, nparts, prec, ksteps):
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_F64 if prec == "f64" else fa.PREC_MIXED)
+    plan = fa.Plan(case.mesh, fa.PREC_F64 if prec == "f64" else fa.PREC_F32, part=case.part, ksteps=ksteps,
+                   assemble=True)
+    host_coef = plan.coef()                           # packed from the host-assembled MeshStats
+    plan.assemble()
+    tol = 1e-11 if prec == "f64" else 2e-5
+    st = case.ostats(ol.F64 if prec == "f64" else ol.MIXED)
+    check_records(plan.face_records(), st, case.F, tol)
+    assert abs(plan.max_edge() - st.maxEdgeLen) <= tol * st.maxEdgeLen
+    dev_coef = plan.coef()
+    assert dev_coef.shape == host_coef.shape
+    scale = np.abs(host_coef).max(axis=0)
+    assert (np.abs(dev_coef - host_coef).max(axis=0) <= 20 * tol * scale).all()
+
+
+def deformed(pts, amp, q, phase):
+    s = 1 + amp * np.sin(q * pts[:, 0] + phase) * np.cos(q * pts[:, 1] - 0.5 * phase) * np.sin(q * pts[:, 2] + 0.25 * phase)
+    return pts * s[:, None]
+
+
+@pytest.mark.parametrize("ksteps", [0, 3])
+def test_steps_on_device_assembled_deformed_mesh(ksteps):
+    """BASELINE config 5 shape: deform -> re-assemble on the device -> step, against the oracle
+    assembling the same deformed positions on the CPU"""
+    case = sphere_case(16, 8)
+    case.mesh.init_stats(fa.PREC_F64)
+    plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps, assemble=True)
+    amp, q, phase = 0.03, 0.9, 0.7
+    plan.deform(amp, q, phase)
+    plan.assemble()
+    pts_d = deformed(case.pts, amp, q, phase)
+    st = ol.Stats(case.topo, pts_d, ol.F64)
+    assert abs(plan.max_edge() - st.maxEdgeLen) <= 1e-12 * st.maxEdgeLen
+    check_records(plan.face_records(), st, case.F, 1e-11)
+    dt = 0.1 * st.maxEdgeLen ** 2
+    plan.set_state(case.n0, case.c0)
+    plan.run(6, dt, case.model)
+    n_gpu, c_gpu = plan.get_state()
+    n_ref, c_ref = st.step(case.n0, case.c0, dt, 6, case.model.as_array())
+    assert rel_l2(n_gpu, n_ref) <= 1e-11 and rel_l2(c_gpu, c_ref) <= 1e-11
+    # set_points: new base positions from the host (ordered numbering)
+    plan.set_points(case.pts)
+    plan.assemble()
+    check_records(plan.face_records(), case.ostats(ol.F64), case.F, 1e-11)
+
+
+def test_assembly_requires_flag():
+    case = sphere_case(4, 2)
+    case.mesh.init_stats(fa.PREC_F64)
+    plan = fa.Plan(case.mesh, fa.PREC_F64)
+    with pytest.raises(fa.FemError):
+        plan.assemble()
