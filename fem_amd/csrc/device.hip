@@ -337,7 +337,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void assemble_faces_kernel(const typename Vec<T>::t4 *__restrict__ pos,
                                                              const uint *__restrict__ tri0, const uint *__restrict__ tri1,
                                                              const uint *__restrict__ tri2, typename Vec<T>::t4 *__restrict__ rec,
-                                                             uint F, unsigned long long *__restrict__ maxEdgeBits) {
+                                                             uint F, double *__restrict__ blockMax) {
   typedef typename Vec<T>::t4 T4;
   const uint f = blockIdx.x * blockDim.x + threadIdx.x;
   T me = 0;
@@ -369,44 +369,68 @@ __global__ __launch_bounds__(256) void assemble_faces_kernel(const typename Vec<
     r1.w = me;
     rec[4 * (size_t)f] = r0; rec[4 * (size_t)f + 1] = r1; rec[4 * (size_t)f + 2] = r2; rec[4 * (size_t)f + 3] = r3;
   }
-  // A4: longest edge -> one atomic per wave (positive doubles order like their bit patterns)
+  // A4: longest edge -> wave shuffle reduction, one partial per workgroup (a single-address atomic
+  // per wave would serialise ~F/64 atomics at the memory side); max_reduce_kernel finishes it
+  __shared__ double s_part[4];
   double m = (double)me;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(maxEdgeBits, (unsigned long long)__double_as_longlong(m));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
 }
 
+__global__ __launch_bounds__(1024) void max_reduce_kernel(const double *__restrict__ part, uint n, double *__restrict__ out) {
+  __shared__ double s_part[16];
+  double m = 0;
+  for (uint i = threadIdx.x; i < n; i += 1024) m = fmax(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; i++) m = fmax(m, s_part[i]);
+    *out = m;
+  }
+}
+
+constexpr int kTileWDev = 6;       // entries per row of the tile layout (= kTileW)
 template <typename T> __device__ __forceinline__ T comp(const typename Vec<T>::t4 &v, uint k) {
   return k == 0 ? v.x : (k == 1 ? v.y : v.z);
 }
 
-// one operator row: entries e(k) = first + k * stride, k < width
-template <typename T>
+// One operator row: entries e(k) = first + k * stride, k < width <= W.  Fully unrolled over W so
+// that each phase issues all of its loads before the first use: 2W table words, then W records for
+// the lumped mass / angle sum, then the 2W x 4 record quarters of the edge terms.
+template <typename T, int W>
 __device__ __forceinline__ void assemble_row(const typename Vec<T>::t4 *__restrict__ rec, const uint *__restrict__ topo,
                                              typename Vec<T>::t4 *__restrict__ coef, size_t first, size_t stride, uint width) {
   typedef typename Vec<T>::t4 T4;
-  T area3 = 0, theta = 0;
-  for (uint k = 0; k < width; k++) {
-    const uint t1 = topo[2 * (first + k * stride)];
-    if (t1 != 0xffffffffu) {
-      const T4 r0 = rec[4 * (size_t)(t1 >> 2)];
-      theta += comp<T>(r0, t1 & 3u);
-      area3 += r0.w / 3;
-    }
+  uint t1[W], t2[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint2 t = (uint)k < width ? *reinterpret_cast<const uint2 *>(topo + 2 * (first + k * stride)) : make_uint2(~0u, ~0u);
+    t1[k] = t.x; t2[k] = t.y;
   }
-  for (uint k = 0; k < width; k++) {
-    const size_t e = first + k * stride;
-    const uint t1 = topo[2 * e], t2 = topo[2 * e + 1];
+  T4 q0[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) q0[k] = rec[4 * (size_t)(t1[k] == ~0u ? 0 : t1[k] >> 2)];
+  T area3 = 0, theta = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++)
+    if (t1[k] != ~0u) { theta += comp<T>(q0[k], t1[k] & 3u); area3 += q0[k].w / 3; }
+#pragma unroll
+  for (int k = 0; k < W; k++) {
     T w = 0, cx = 0, cy = 0, cz = 0;
 #pragma unroll
     for (int side = 0; side < 2; side++) {
-      const uint t = side == 0 ? t1 : t2;
-      if (t == 0xffffffffu) continue;
-      const size_t f = t >> 2;
+      const uint t = side == 0 ? t1[k] : t2[k];
+      const size_t f = t == ~0u ? 0 : t >> 2;
       const uint cv = t & 3u;
       const uint cj = side == 0 ? (cv + 1) % 3 : (cv + 2) % 3;       // corner of the neighbour j
       const uint co = 3 - cv - cj;                                    // corner opposite the edge (v, j)
-      const T4 r0 = rec[4 * f], r1 = rec[4 * f + 1], g12 = rec[4 * f + 2], g13 = rec[4 * f + 3];
+      const T4 r0 = side == 0 ? q0[k] : rec[4 * f], r1 = rec[4 * f + 1], g12 = rec[4 * f + 2], g13 = rec[4 * f + 3];
+      if (t == ~0u) continue;
       w += comp<T>(r1, co);
       const T a = comp<T>(r0, cv);
       const T gx = cj == 0 ? g12.x : (cj == 1 ? g13.x : -(g12.x + g13.x));
@@ -417,8 +441,8 @@ __device__ __forceinline__ void assemble_row(const typename Vec<T>::t4 *__restri
     T4 o;
     o.x = area3 > 0 ? w / (2 * area3) : (T)0;
     if (theta > 0) { o.y = cx / theta; o.z = cy / theta; o.w = cz / theta; } else { o.y = o.z = o.w = 0; }
-    if (t1 == 0xffffffffu && t2 == 0xffffffffu) { o.x = o.y = o.z = o.w = 0; }
-    coef[e] = o;
+    if (t1[k] == ~0u && t2[k] == ~0u) { o.x = o.y = o.z = o.w = 0; }
+    if ((uint)k < width) coef[first + k * stride] = o;
   }
 }
 
@@ -429,7 +453,9 @@ __global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename 
   const uint slice = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
   if (slice >= nslices) return;
   const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
-  assemble_row<T>(rec, topo, coef, (size_t)off + lane, 64, width);
+  if (width <= 6) assemble_row<T, 6>(rec, topo, coef, (size_t)off + lane, 64, width);
+  else if (width <= 12) assemble_row<T, 12>(rec, topo, coef, (size_t)off + lane, 64, width);
+  else assemble_row<T, 32>(rec, topo, coef, (size_t)off + lane, 64, width < 32 ? width : 32);   // valence <= 32
 }
 
 template <typename T>
@@ -438,7 +464,7 @@ __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename 
                                                                  typename Vec<T>::t4 *__restrict__ coef, uint W) {
   const uint *mt = meta + 16 * (size_t)blockIdx.x;
   const uint roff = mt[2], rpad = mt[3], rows = mt[5 + mt[4] - 1];
-  for (uint r = threadIdx.x; r < rows; r += blockDim.x) assemble_row<T>(rec, topo, coef, (size_t)roff + r, rpad, W);
+  for (uint r = threadIdx.x; r < rows; r += blockDim.x) assemble_row<T, kTileWDev>(rec, topo, coef, (size_t)roff + r, rpad, W);
 }
 
 // seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
@@ -518,7 +544,7 @@ struct fem_plan {
   fem_uint F = 0, Vg = 0;
   DevBuf<fem_uint> tri0, tri1, tri2, topo;
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
-  unsigned long long *maxedge = nullptr;
+  double *maxedge = nullptr, *blockmax = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
   void *state[2] = {nullptr, nullptr};   // deviations from (base_n, base_c), interleaved
   int cur = 0;
@@ -536,7 +562,8 @@ template <typename T> static int setPoints(fem_plan *p, const double *pts) {
 template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
   typedef typename Vec<T>::t4 T4;
   hipLaunchKernelGGL(assemble_faces_kernel<T>, dim3((p->F + 255) / 256), dim3(256), 0, st, (const T4 *)p->pos, p->tri0.p,
-                     p->tri1.p, p->tri2.p, (T4 *)p->rec, p->F, p->maxedge);
+                     p->tri1.p, p->tri2.p, (T4 *)p->rec, p->F, p->blockmax);
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, (p->F + 255) / 256, p->maxedge);
   if (p->ksteps > 0)
     hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(p->ntiles), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
                        p->tmeta.p, (T4 *)p->tcoef, (fem_uint)kTileW);
@@ -723,7 +750,7 @@ void fem_plan_destroy(fem_plan *p) {
   p->slice_off.release(); p->idx.release(); p->send_idx.release();
   p->tmeta.release(); p->tghost.release(); p->tidx2.release();
   p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release();
-  for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge}) if (q) (void)hipFree(q);
+  for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
@@ -804,7 +831,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     ok(p->tri0.alloc(p->F)) && ok(p->tri0.upload(t0.data())) && ok(p->tri1.alloc(p->F)) && ok(p->tri1.upload(t1.data())) &&
     ok(p->tri2.alloc(p->F)) && ok(p->tri2.upload(t2.data())) && ok(p->topo.alloc(topo.size())) && ok(p->topo.upload(topo.data())) &&
     ok(hipMalloc(&p->pos, 4 * sb * p->Vg)) && ok(hipMalloc(&p->pos0, 4 * sb * p->Vg)) &&
-    ok(hipMalloc(&p->rec, 16 * sb * (p->F ? p->F : 1))) && ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8));
+    ok(hipMalloc(&p->rec, 16 * sb * (p->F ? p->F : 1))) && ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8)) &&
+    ok(hipMalloc((void **)&p->blockmax, 8 * (size_t)((p->F + 255) / 256 + 1)));
   }
   if (e == hipSuccess && shard)
     ok(p->send_idx.alloc(shard->send_idx.size())) && (shard->send_idx.empty() || ok(p->send_idx.upload(shard->send_idx.data())));
@@ -951,7 +979,6 @@ int fem_plan_set_points(fem_plan *p, const double *points) {
 
 int fem_plan_assemble(fem_plan *p, void *stream) {
   if (!p || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_assemble: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
-  HIP_TRY(hipMemsetAsync(p->maxedge, 0, 8, (hipStream_t)stream));
   if (p->precision == FEM_PREC_F32) launchAssemble<float>(p, (hipStream_t)stream);
   else launchAssemble<double>(p, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
