@@ -139,12 +139,22 @@ static void fo_compute_laplacian_weights(int V, int F, int H, const int32_t *opp
  * lap[i] = fn[i] wVtx[i] + sum over outgoing half-edges fn[to] wHej[h]. */
 void fo_laplacian(int V, const int32_t *rowptr, const uint32_t *col, const int32_t *row_he,
                   const double *fn, double *lap, const double *wHej, const double *wVtx) {
-  int i, e;
+  int i;
+#pragma omp parallel for schedule(static)
   for (i = 0; i < V; i++) {
+    int e;
     lap[i] = fn[i] * wVtx[i];
     for (e = rowptr[i]; e < rowptr[i + 1]; e++) lap[i] += fn[col[e]] * wHej[row_he[e]];
   }
 }
+
+/* threads used by the step loops (1 unless built with -fopenmp); for the cpu_baseline leg */
+#ifdef _OPENMP
+#include <omp.h>
+int fo_set_threads(int n) { if (n > 0) omp_set_num_threads(n); return omp_get_max_threads(); }
+#else
+int fo_set_threads(int n) { (void)n; return 1; }
+#endif
 
 /* ------------------------------------------------------------------ */
 /* Assembly + step, generated twice (geometry type float / double).    */

@@ -116,6 +116,15 @@ class Stats:
         return n, c
 
 
+def set_threads(n):
+    """threads of the OpenMP step loops (cpu_baseline leg); returns the count in effect"""
+    return lib.fo_set_threads(C.c_int(n))
+
+
+set_threads(1)          # tests run the oracle serially: results do not depend on the thread count,
+                        # timing should not depend on the machine
+
+
 def initial_condition(V, seed=1, nMax=1.0):
     n, c = np.empty(V), np.empty(V)
     lib.fo_initial_condition(C.c_int(V), C.c_uint32(seed), C.c_double(nMax), _p(n, f64p), _p(c, f64p))
