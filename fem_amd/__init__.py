@@ -412,6 +412,14 @@ class Plan:
         _check(lib.fem_plan_download_coef(self.h, _ptr(out, f64p)))
         return out.reshape(-1, 4)
 
+    def format(self, nverts=None):
+        """-> (rgba float64 [V,4], rgb uint8 [V,3], nmin, nmax): the reference's colour map of n"""
+        V = nverts or self.V
+        rgba, rgb = np.empty((V, 4)), np.empty((V, 3), np.uint8)
+        lo, hi = C.c_double(), C.c_double()
+        _check(lib.fem_plan_format(self.h, C.c_uint32(V), _ptr(rgba, f64p), _ptr(rgb, u8p), C.byref(lo), C.byref(hi)))
+        return rgba, rgb, lo.value, hi.value
+
     def tile_info(self):
         k, thr, rpt = C.c_int(), C.c_int(), C.c_int()
         nt, ml, rows = C.c_uint32(), C.c_uint32(), C.c_uint64()

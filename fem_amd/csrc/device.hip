@@ -479,6 +479,53 @@ __global__ __launch_bounds__(256) void deform_kernel(const typename Vec<T>::t4 *
   pos[i] = p;
 }
 
+
+// ---------------------------------------------------------------------------
+// Result output (formatKernel + the two thrust reductions of format(), reference
+// src/FEM_common.cu:183-230, without GL): min/max of n over the vertices, then
+// RGBA = (n^, 1 - n^, 1 - n^, 1) with n^ = (n - min) / (max - min).
+// ---------------------------------------------------------------------------
+template <typename T2>
+__global__ __launch_bounds__(256) void minmax_kernel(const T2 *__restrict__ state, uint V, double *__restrict__ part) {
+  __shared__ double s_lo[4], s_hi[4];
+  double lo = 1e300, hi = -1e300;
+  for (uint i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
+    const double x = (double)state[i].x;
+    lo = fmin(lo, x); hi = fmax(hi, x);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
+    part[2 * blockIdx.x + 1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
+  }
+}
+
+__global__ __launch_bounds__(256) void minmax_final_kernel(const double *__restrict__ part, uint n, double *__restrict__ out) {
+  __shared__ double s_lo[4], s_hi[4];
+  double lo = 1e300, hi = -1e300;
+  for (uint i = threadIdx.x; i < n; i += 256) { lo = fmin(lo, part[2 * i]); hi = fmax(hi, part[2 * i + 1]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
+  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
+    out[1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
+  }
+}
+
+template <typename T2>
+__global__ __launch_bounds__(256) void format_kernel(const T2 *__restrict__ state, uint V, const double *__restrict__ mm,
+                                                     double4 *__restrict__ rgba) {
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V) return;
+  const double n = ((double)state[i].x - mm[0]) / (mm[1] - mm[0]);
+  rgba[i] = make_double4(n, 1 - n, 1 - n, 1.0);
+}
+
 // halo pack: dst[i] = state[send_idx[i]] (8 or 16 B per lane, coalesced stores)
 template <typename T2>
 __global__ __launch_bounds__(256) void pack_halo_kernel(const T2 *__restrict__ state, const uint *__restrict__ send_idx,
@@ -1021,6 +1068,46 @@ int fem_plan_download_coef(fem_plan *p, double *out) {
   const void *dev = p->ksteps > 0 ? p->tcoef : p->coef;
   const size_t n = fem_plan_coef_count(p);
   return p->precision == FEM_PREC_F32 ? downloadAs<float>(dev, n, out) : downloadAs<double>(dev, n, out);
+}
+
+
+// ---- result output ------------------------------------------------------------------------------------
+
+int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *rgb, double *nmin, double *nmax) {
+  if (!p || nverts == 0 || nverts > p->V) return fail(FEM_ERR_INVALID, "fem_plan_format: bad vertex count");
+  const fem_uint V = nverts, nb = std::min<fem_uint>((V + 255) / 256, 1024);
+  double *part = nullptr, *mm = nullptr;
+  double4 *out = nullptr;
+  hipError_t e = hipMalloc((void **)&part, 16 * (size_t)nb);
+  if (e == hipSuccess) e = hipMalloc((void **)&mm, 16);
+  if (e == hipSuccess) e = hipMalloc((void **)&out, sizeof(double4) * (size_t)V);
+  if (e == hipSuccess) {
+    if (p->precision == FEM_PREC_F32) hipLaunchKernelGGL(minmax_kernel<float2>, dim3(nb), dim3(256), 0, 0, (const float2 *)p->state[p->cur], V, part);
+    else hipLaunchKernelGGL(minmax_kernel<double2>, dim3(nb), dim3(256), 0, 0, (const double2 *)p->state[p->cur], V, part);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, 0, (const double *)part, nb, mm);
+    if (p->precision == FEM_PREC_F32) hipLaunchKernelGGL(format_kernel<float2>, dim3((V + 255) / 256), dim3(256), 0, 0, (const float2 *)p->state[p->cur], V, (const double *)mm, out);
+    else hipLaunchKernelGGL(format_kernel<double2>, dim3((V + 255) / 256), dim3(256), 0, 0, (const double2 *)p->state[p->cur], V, (const double *)mm, out);
+    e = hipDeviceSynchronize();
+  }
+  std::vector<double> h;
+  double hmm[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpy(hmm, mm, 16, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && (rgba || rgb)) {
+    h.resize(4 * (size_t)V);
+    e = hipMemcpy(h.data(), out, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
+  }
+  for (void *q : {(void *)part, (void *)mm, (void *)out}) if (q) (void)hipFree(q);
+  if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "fem_plan_format", e);
+  if (rgba) memcpy(rgba, h.data(), sizeof(double) * h.size());
+  if (rgb)      // 8-bit colours as in ResultantPattern.off: components truncated, so R + G = 254 or 255
+    for (size_t i = 0; i < V; i++)
+      for (int k = 0; k < 3; k++) {
+        const double c = 255.0 * h[4 * i + k];
+        rgb[3 * i + k] = (unsigned char)(c < 0 ? 0 : (c > 255 ? 255 : c));
+      }
+  if (nmin) *nmin = hmm[0] + p->base_n;     // the buffers hold deviations from base_n
+  if (nmax) *nmax = hmm[1] + p->base_n;
+  return FEM_OK;
 }
 
 int fem_plan_tile_info(const fem_plan *p, int *ksteps, fem_uint *ntiles, fem_uint *max_local, uint64_t *rows_loaded,

@@ -245,6 +245,14 @@ int fem_plan_face_records(fem_plan *p, double *rec16F);
 /* the plan's operator array (4 values per entry, layout order), for comparing host- and device-assembled operators */
 uint64_t fem_plan_coef_count(const fem_plan *p);
 int fem_plan_download_coef(fem_plan *p, double *out);
+/* Replaces `extern "C" void format(double2*, cudaGraphicsResource_t*, int)`, FEM_common.h:27-31 /
+ * FEM_common.cu:181-230, without the GL interop: min/max of n over the first `nverts` vertices of the
+ * current state (two device reductions, as thrust::min/max_element at :208-209), then
+ * RGBA = (n^, 1-n^, 1-n^, 1), n^ = (n-min)/(max-min) (formatKernel, :183-194).  Outputs (host, any may
+ * be NULL): rgba[4*nverts] doubles; rgb[3*nverts] 8-bit colours truncated as in ResultantPattern.off;
+ * the extrema of n.  Synchronises.  Pass the result to fem_off_write for a COFF file. */
+int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *rgb, double *nmin,
+                    double *nmax);
 /* geometry of a tiled plan: fused steps, tile count, largest tile (rows staged in LDS), operator
  * rows loaded per launch (sum over tiles), workgroup size and rows per thread; ksteps = 0 for a
  * sliced-ELL plan.  Any out-pointer may be NULL. */

@@ -87,3 +87,31 @@ def test_hip_step_reproduces_the_pattern():
     n32, _ = plan.get_state()
     col = colours_of(n32[case.part.perm_v])
     assert np.corrcoef(col, R)[0, 1] >= 0.999 and np.abs(col - R).max() <= 10
+
+
+@pytest.mark.gpu
+def test_format_and_coff_writer(tmp_path):
+    """format() (FEM_common.cu:181-230) on the device + COFF output in the shape of ResultantPattern.off"""
+    pts, tri, rgb_file = fa.off_read(PATH)
+    case = Case(pts, tri, 3)
+    case.mesh.init_stats(fa.PREC_F64)
+    n0, c0 = ol.initial_condition(case.V, 1)
+    n_ord, c_ord = np.empty_like(n0), np.empty_like(c0)
+    n_ord[case.part.perm_v], c_ord[case.part.perm_v] = n0, c0
+    for prec, tol in ((fa.PREC_F64, 1e-12), (fa.PREC_F32, 1e-5)):
+        plan = fa.Plan(case.mesh, prec, alt_model())
+        plan.set_state(n_ord, c_ord)
+        plan.run(STEPS, case.dt, alt_model())
+        n, c = plan.get_state()
+        rgba, rgb, lo, hi = plan.format()
+        ref = ol.colour_map(np.stack([n, c], axis=1))
+        assert np.abs(rgba - ref).max() <= tol
+        assert abs(lo - n.min()) <= tol and abs(hi - n.max()) <= tol
+        assert np.array_equal(rgb[:, 1], rgb[:, 2]) and set(np.unique(rgb[:, 0].astype(int) + rgb[:, 1])) <= {254, 255}
+    # write in file order and compare with the reference's artefact
+    out = str(tmp_path / "pattern.off")
+    fa.off_write(out, pts, tri, rgb[case.part.perm_v])
+    p2, t2, c2 = fa.off_read(out)
+    assert np.array_equal(t2, tri) and np.allclose(p2, pts)
+    assert np.abs(c2.astype(int) - rgb_file.astype(int)).max() <= 10
+    assert open(out).readline().strip() == "COFF"
