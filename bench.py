@@ -25,6 +25,10 @@ WORKLOADS = {                       # class-I geodesic spheres, edge ~ 0.1 (BASE
     "sphere1m": dict(nu=320, verts_per_part=256),        # config 2
     "sphere4m": dict(nu=640, verts_per_part=256),
     "sphere16m": dict(nu=1280, verts_per_part=256),      # config 3 / north-star roofline size
+    # config 4 stand-in (no scan data ships with the reference or this image): irregular valences
+    # 3..16, local high-valence fans, radial noise; 8.1M vertices
+    "scan8m": dict(nu=900, verts_per_part=256, scanned=True),
+    "scan500k": dict(nu=224, verts_per_part=256, scanned=True),
 }
 ALG_BYTES_PER_VERTEX_STEP = 168     # V*24 + nnz*8 + F*48 on a closed genus-0 mesh
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -99,18 +103,20 @@ def main():
 
     wl = WORKLOADS[args.workload]
     t_host = time.perf_counter()
-    pts, tri = fa.make_icosphere(wl["nu"], 0.1)
+    scanned = wl.get("scanned", False)
+    pts, tri = fa.make_scanned_like(wl["nu"], 0.1, seed=3) if scanned else fa.make_icosphere(wl["nu"], 0.1)
     mesh = fa.Mesh(pts, tri)
     V_total = mesh.V
+    dt_rule = "stable" if scanned else "reference"
     # fused tiles: partition size such that a partition + (fuse-1) rings fits the register tile
     tile_n0 = int(os.environ.get("FEM_TILE_N0", "620"))
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     if world > 1:
         from fem_amd import dist as fdist
-        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse)
+        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse, dt_rule=dt_rule)
     else:
         from fem_amd import dist as fdist
-        runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse)
+        runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse, dt_rule=dt_rule)
     del pts, tri, mesh
     t_host = time.perf_counter() - t_host
 
@@ -148,9 +154,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "%s: class-I geodesic icosphere nu=%d, V=%d, F=%d, %d partitions, "
+            "config": {"workload": "%s: %s nu=%d, V=%d, F=%d, %d partitions, "
                                    "reaction-diffusion explicit Euler, seeded random IC"
-                                   % (args.workload, wl["nu"], V_total, 2 * V_total - 4, nparts),
+                                   % (args.workload, "scanned-like irregular surface (flipped/fanned/noisy geodesic sphere)"
+                                      if scanned else "class-I geodesic icosphere", wl["nu"], V_total, 2 * V_total - 4, nparts),
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "halo_rings": getattr(runner, "krings", None),

@@ -101,6 +101,13 @@ def make_icosphere(nu, edge=0.1):
     return _mesh_out(lib.fem_make_icosphere, C.c_int(nu), C.c_double(edge))
 
 
+def make_scanned_like(nu, edge=0.1, seed=1, flip_fraction=0.1, noise_amp=0.1, high_valence_fraction=0.001,
+                      high_valence=16):
+    return _mesh_out(lib.fem_make_scanned_like, C.c_int(nu), C.c_double(edge), C.c_uint32(seed),
+                     C.c_double(flip_fraction), C.c_double(noise_amp), C.c_double(high_valence_fraction),
+                     C.c_int(high_valence))
+
+
 def make_strip(nx=11, ny=41, h=0.1):
     return _mesh_out(lib.fem_make_strip, C.c_int(nx), C.c_int(ny), C.c_double(h))
 

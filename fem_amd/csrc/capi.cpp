@@ -70,6 +70,15 @@ int fem_make_icosphere(int nu, double edge, int *V, int *F, double **points, fem
   return exportMesh(m, V, F, points, tri);
 }
 
+int fem_make_scanned_like(int nu, double edge, fem_uint seed, double flip_fraction, double noise_amp,
+                          double high_valence_fraction, int high_valence, int *V, int *F, double **points,
+                          fem_uint **tri) {
+  fem::SimpleTriMesh m;
+  int rc = fem::makeScannedLike(nu, edge, seed, flip_fraction, noise_amp, high_valence_fraction, high_valence, m);
+  if (rc != FEM_OK) return fail(rc, "fem_make_scanned_like: bad argument");
+  return exportMesh(m, V, F, points, tri);
+}
+
 int fem_make_strip(int nx, int ny, double h, int *V, int *F, double **points, fem_uint **tri) {
   fem::SimpleTriMesh m;
   int rc = fem::makeStrip(nx, ny, h, m);

@@ -210,11 +210,12 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
 // vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
 // ---------------------------------------------------------------------------
-template <typename T, int TPB, int R, int W, int MINW>
+template <typename T, int TPB, int R, int W, int MINW, bool X>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
-    const typename Vec<T>::t4 *__restrict__ coef, uint ntiles, uint maxLocal, int nsteps, ModelT<T> m) {
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint ntiles, uint maxLocal,
+    uint maxExtra, int nsteps, ModelT<T> m) {
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   extern __shared__ __align__(16) unsigned char tile_smem[];
@@ -225,6 +226,10 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   const uint n0 = mt[5], mk = mt[5 + k];
   T2 *cur = reinterpret_cast<T2 *>(tile_smem);
   T2 *nxt = cur + maxLocal;
+  // rows wider than W (irregular meshes): entries W, W+1, ... of all rows of the tile, in LDS
+  T4 *xs_coef = reinterpret_cast<T4 *>(nxt + maxLocal);          // maxLocal is even: 16-B aligned
+  uint *xs_off = reinterpret_cast<uint *>(xs_coef + maxExtra);
+  const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // X = false: plan without wide rows
   const uint t = threadIdx.x;
 
   // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
@@ -242,6 +247,17 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     for (int w = 0; w < W; w++) cf[q][w] = tcoef[w * rpad + r];
 #pragma unroll
     for (int w = 0; w < W / 2; w++) ix[q][w] = tidx[w * rpad + r] * (uint)sizeof(T2);   // ids < 4096: both halves scale
+  }
+  uint xi[R];                                            // first extra | count << 16 of each row
+#pragma unroll
+  for (int q = 0; q < R; q++) xi[q] = 0;
+  if (X && xcnt) {                                       // tile-uniform
+#pragma unroll
+    for (int q = 0; q < R; q++) xi[q] = xinfo[xoff + min(t + TPB * q, rpad - 1)];
+    for (uint i = t; i < xcnt; i += TPB) {
+      xs_coef[i] = tcoef[W * rpad + i];
+      xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
+    }
   }
   constexpr int SU = 4;                                  // state slots per thread per pass
   for (uint i0 = 0; i0 < mk; i0 += SU * TPB) {
@@ -281,6 +297,15 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
           const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);   // byte offset in the buffer
           const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
           const T4 c = cf[q][w];
+          const T dn = f.x - self.x, dc = f.y - self.y;
+          lapn += c.x * dn; lapc += c.x * dc;
+          gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+          gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+        }
+        if (X)
+        for (uint e = xi[q] & 0xffffu, ee = e + (xi[q] >> 16); e < ee; e++) {
+          const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
+          const T4 c = xs_coef[e];
           const T dn = f.x - self.x, dc = f.y - self.y;
           lapn += c.x * dn; lapc += c.x * dc;
           gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
@@ -402,14 +427,17 @@ template <typename T> __device__ __forceinline__ T comp(const typename Vec<T>::t
 // One operator row: entries e(k) = first + k * stride, k < width <= W.  Fully unrolled over W so
 // that each phase issues all of its loads before the first use: 2W table words, then W records for
 // the lumped mass / angle sum, then the 2W x 4 record quarters of the edge terms.
-template <typename T, int W>
+// Entries k >= SPLIT (the tile layout's extras of a wide row) live at xfirst + (k - SPLIT).
+template <typename T, int W, int SPLIT = W>
 __device__ __forceinline__ void assemble_row(const typename Vec<T>::t4 *__restrict__ rec, const uint *__restrict__ topo,
-                                             typename Vec<T>::t4 *__restrict__ coef, size_t first, size_t stride, uint width) {
+                                             typename Vec<T>::t4 *__restrict__ coef, size_t first, size_t stride, uint width,
+                                             size_t xfirst = 0) {
   typedef typename Vec<T>::t4 T4;
+  auto at = [&](int k) { return k < SPLIT ? first + k * stride : xfirst + (size_t)(k - SPLIT); };
   uint t1[W], t2[W];
 #pragma unroll
   for (int k = 0; k < W; k++) {
-    const uint2 t = (uint)k < width ? *reinterpret_cast<const uint2 *>(topo + 2 * (first + k * stride)) : make_uint2(~0u, ~0u);
+    const uint2 t = (uint)k < width ? *reinterpret_cast<const uint2 *>(topo + 2 * at(k)) : make_uint2(~0u, ~0u);
     t1[k] = t.x; t2[k] = t.y;
   }
   T4 q0[W];
@@ -442,7 +470,7 @@ __device__ __forceinline__ void assemble_row(const typename Vec<T>::t4 *__restri
     o.x = area3 > 0 ? w / (2 * area3) : (T)0;
     if (theta > 0) { o.y = cx / theta; o.z = cy / theta; o.w = cz / theta; } else { o.y = o.z = o.w = 0; }
     if (t1[k] == ~0u && t2[k] == ~0u) { o.x = o.y = o.z = o.w = 0; }
-    if ((uint)k < width) coef[first + k * stride] = o;
+    if ((uint)k < width) coef[at(k)] = o;
   }
 }
 
@@ -461,10 +489,17 @@ __global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename 
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ rec,
                                                                  const uint *__restrict__ topo, const uint *__restrict__ meta,
+                                                                 const uint *__restrict__ xinfo,
                                                                  typename Vec<T>::t4 *__restrict__ coef, uint W) {
   const uint *mt = meta + 16 * (size_t)blockIdx.x;
-  const uint roff = mt[2], rpad = mt[3], rows = mt[5 + mt[4] - 1];
-  for (uint r = threadIdx.x; r < rows; r += blockDim.x) assemble_row<T, kTileWDev>(rec, topo, coef, (size_t)roff + r, rpad, W);
+  const uint roff = mt[2], rpad = mt[3], rows = mt[5 + mt[4] - 1], xoff = mt[14], xcnt = mt[15];
+  for (uint r = threadIdx.x; r < rows; r += blockDim.x) {
+    const uint xi = xcnt ? xinfo[xoff + r] : 0u, nx = xi >> 16;
+    const size_t first = (size_t)roff + r, xfirst = (size_t)roff + (size_t)W * rpad + (xi & 0xffffu);
+    if (nx == 0) assemble_row<T, kTileWDev>(rec, topo, coef, first, rpad, W);
+    else if (nx <= 6) assemble_row<T, 12, kTileWDev>(rec, topo, coef, first, rpad, W + nx, xfirst);
+    else assemble_row<T, 32, kTileWDev>(rec, topo, coef, first, rpad, W + (nx < 26 ? nx : 26), xfirst);   // valence <= 32
+  }
 }
 
 // seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
@@ -558,6 +593,7 @@ size_t pitchFor(size_t widthBytes) { return (widthBytes + 511) / 512 * 512; }   
 // 0 = 512 x 2 is the measured best: no spills, 2 workgroups per CU, 1024 register-resident rows per tile).
 constexpr int kTileW = 6;
 constexpr fem_uint kTileMaxLocal = 4096;
+constexpr fem_uint kTileMaxExtra = 1536;  // LDS-resident overflow entries per tile (rows with more than kTileW neighbours)
 struct TileCfg { int tpb, r, minw; };
 constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}};
 constexpr int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
@@ -581,10 +617,10 @@ struct fem_plan {
   DevBuf<fem_uint> slice_off, idx, send_idx;
   // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
   int ksteps = 0, tcfg = 0;
-  fem_uint ntiles = 0, maxLocal = 0;
-  uint64_t tile_rows = 0;
+  fem_uint ntiles = 0, maxLocal = 0, maxExtra = 0;
+  uint64_t tile_rows = 0, tile_entries = 0;
   uint64_t tile_bytes = 0;
-  DevBuf<fem_uint> tmeta, tghost, tidx2;
+  DevBuf<fem_uint> tmeta, tghost, tidx2, txinfo;
   void *tcoef = nullptr;
   // device assembly (FEM_PLAN_DEVICE_ASSEMBLY): connectivity SoA, positions, per-face records, entry tables
   bool can_assemble = false;
@@ -613,7 +649,7 @@ template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
   hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, (p->F + 255) / 256, p->maxedge);
   if (p->ksteps > 0)
     hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(p->ntiles), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
-                       p->tmeta.p, (T4 *)p->tcoef, (fem_uint)kTileW);
+                       p->tmeta.p, p->txinfo.p, (T4 *)p->tcoef, (fem_uint)kTileW);
   else
     hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(p->nblocks), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
                        p->slice_off.p, (T4 *)p->coef, p->nslices);
@@ -633,14 +669,15 @@ static hipError_t launchTile(fem_plan *p, const void *src, void *dst, int nsteps
   typedef typename Vec<T>::t4 T4;
   constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
   constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : (TPB == 512 ? 2 : 1);
-  auto kern = tile_step_kernel<T, TPB, R, kTileW, MINW>;
-  const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2);
+  auto kern = p->maxExtra ? tile_step_kernel<T, TPB, R, kTileW, MINW, true> : tile_step_kernel<T, TPB, R, kTileW, MINW, false>;
+  const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(kern, dim3(p->ntiles), dim3(TPB), lds, stream, (const T2 *)src, (T2 *)dst, p->tmeta.p,
-                     p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->ntiles, p->maxLocal, nsteps, m);
+                     p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra,
+                     nsteps, m);
   return hipSuccess;
 }
 
@@ -795,7 +832,7 @@ void fem_ref_device_args(const fem_ref_device *d, uint64_t *fn_one, uint64_t *fn
 void fem_plan_destroy(fem_plan *p) {
   if (!p) return;
   p->slice_off.release(); p->idx.release(); p->send_idx.release();
-  p->tmeta.release(); p->tghost.release(); p->tidx2.release();
+  p->tmeta.release(); p->tghost.release(); p->tidx2.release(); p->txinfo.release();
   p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release();
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
@@ -833,8 +870,9 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     const char *cfgEnv = getenv("FEM_TILE_CONFIG");
     tcfg = cfgEnv ? atoi(cfgEnv) : 0;
     if (tcfg < 0 || tcfg >= kNumTileCfgs) return fail(FEM_ERR_INVALID, "FEM_TILE_CONFIG out of range");
-    rc = fem::packTileLayout(op, ranges, ksteps, kTileCfgs[tcfg].tpb, kTileCfgs[tcfg].r, kTileW, kTileMaxLocal, TL);
-    if (rc == FEM_ERR_LIMIT) return fail(rc, "fem_plan_create_tiled: a row has more than 6 neighbours (fused kernel limit)");
+    rc = fem::packTileLayout(op, ranges, ksteps, kTileCfgs[tcfg].tpb, kTileCfgs[tcfg].r, kTileW,
+                             precision == FEM_PREC_F32 ? kTileMaxLocal : kTileMaxLocal * 3 / 4, kTileMaxExtra, TL);
+    if (rc == FEM_ERR_LIMIT) return fail(rc, "fem_plan_create_tiled: a partition cannot be cut into tiles that fit the fused kernel");
     if (rc != FEM_OK) return fail(rc, "fem_plan_create_tiled: cannot tile");
   } else {
     rc = fem::packSellLayout(op, L);
@@ -856,11 +894,14 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     }
   };
   if (ksteps > 0) {
-    p->ksteps = ksteps; p->ntiles = TL.ntiles; p->maxLocal = TL.maxLocal; p->tcfg = tcfg; p->tile_rows = TL.rowSteps;
-    p->tile_bytes = (uint64_t)(TL.coef.size() / 4) * (4 * sb + 2) + (uint64_t)TL.ghost.size() * 4 + (uint64_t)TL.meta.size() * 4;
+    p->ksteps = ksteps; p->ntiles = TL.ntiles; p->tcfg = tcfg; p->tile_rows = TL.rowSteps;
+    p->maxLocal = (TL.maxLocal + 1) & ~1u; p->maxExtra = TL.maxExtra; p->tile_entries = TL.coef.size() / 4;
+    p->tile_bytes = (uint64_t)(TL.coef.size() / 4) * (4 * sb + 2) + (uint64_t)TL.ghost.size() * 4 + (uint64_t)TL.meta.size() * 4 +
+                    (uint64_t)TL.xinfo.size() * 4;
     ok(p->tmeta.alloc(TL.meta.size())) && ok(p->tmeta.upload(TL.meta.data())) &&
     ok(p->tghost.alloc(TL.ghost.size())) && (TL.ghost.empty() || ok(p->tghost.upload(TL.ghost.data()))) &&
-    ok(p->tidx2.alloc(TL.idx2.size())) && ok(p->tidx2.upload(TL.idx2.data()));
+    ok(p->tidx2.alloc(TL.idx2.size())) && ok(p->tidx2.upload(TL.idx2.data())) &&
+    ok(p->txinfo.alloc(TL.xinfo.size())) && ok(p->txinfo.upload(TL.xinfo.data()));
     uploadCoef(&p->tcoef, TL.coef);
   } else {
     p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4; p->entries = L.idx.size();
@@ -1060,7 +1101,7 @@ int fem_plan_face_records(fem_plan *p, double *rec16F) {
 
 uint64_t fem_plan_coef_count(const fem_plan *p) {
   if (!p) return 0;
-  return p->ksteps > 0 ? (uint64_t)p->tidx2.n * 2 * 4 : (uint64_t)p->entries * 4;
+  return p->ksteps > 0 ? p->tile_entries * 4 : (uint64_t)p->entries * 4;
 }
 
 int fem_plan_download_coef(fem_plan *p, double *out) {

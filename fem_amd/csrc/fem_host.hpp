@@ -96,6 +96,8 @@ int readOFF(const std::string &path, SimpleTriMesh &m);
 int writeOFF(const std::string &path, const SimpleTriMesh &m);
 int makeIcosphere(int nu, double edge, SimpleTriMesh &m);
 int makeStrip(int nx, int ny, double h, SimpleTriMesh &m);
+int makeScannedLike(int nu, double edge, uint seed, double flipFraction, double noiseAmp, double highValFraction,
+                    int highVal, SimpleTriMesh &m);
 void initialCondition(int V, uint seed, double nMax, double *nFn, double *cFn);
 
 // Reference device layout (initializeGPUData, main.cpp:207-342), dense host form.
@@ -136,16 +138,17 @@ int packSellLayout(const RowOp &op, SellLayout &out);
 // Tiles of the fused k-step kernel (pack.cpp).
 struct TileLayout {
   int ksteps = 0;
-  uint T = 0, R = 0, W = 0, ntiles = 0, maxLocal = 0;
+  uint T = 0, R = 0, W = 0, ntiles = 0, maxLocal = 0, maxExtra = 0;
   uint64_t rowSteps = 0;                     // sum over tiles of m[k-1] (rows loaded per launch)
   std::vector<uint> meta;                    // [ntiles][16]
   std::vector<uint> ghost;                   // row ids of the ring rows of every tile
   std::vector<uint> idx2;                    // packed 16-bit local column ids
+  std::vector<uint> xinfo;                   // rows wider than W: per-row (first | count << 16), then column ids
   std::vector<double> coef;                  // [4*entries]
   std::vector<uint> topo;                    // [2*entries] (f1, f2) of RowOp, for device assembly
 };
 int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ranges, int ksteps, uint T, uint R,
-                   uint W, uint maxLocal, TileLayout &out);
+                   uint W, uint maxLocal, uint maxExtra, TileLayout &out);
 
 // One rank's share of an ordered mesh: a contiguous range of partitions (hence of vertices),
 // plus the ghost vertices within `krings` edges of it, and who sends what to whom.

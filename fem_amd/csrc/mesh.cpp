@@ -257,6 +257,129 @@ int makeIcosphere(int nu, double edge, SimpleTriMesh &m) {
   return (int64_t)m.n_faces() == F ? FEM_OK : FEM_ERR_INVALID;
 }
 
+
+// "Scanned-like" irregular surface (BASELINE config 4; no scan data ships with the reference or the
+// container): a geodesic sphere with seeded random edge flips (irregular valences), a fraction of
+// vertices driven to valence >= highVal by flipping the edges of their 1-ring towards them
+// (local fans), and seeded radial noise.  Flips act on the half-edge tables in O(1); the result is
+// still a closed oriented 2-manifold.
+int makeScannedLike(int nu, double edge, uint seed, double flipFraction, double noiseAmp, double highValFraction,
+                    int highVal, SimpleTriMesh &m) {
+  int rc = makeIcosphere(nu, edge, m);
+  if (rc != FEM_OK) return rc;
+  if (flipFraction < 0 || noiseAmp < 0 || noiseAmp >= 0.5 || highValFraction < 0 || highVal < 3) return FEM_ERR_INVALID;
+  rc = m.update_topology();
+  if (rc != FEM_OK) return rc;
+  const uint V = m.n_vertices(), F = m.n_faces();
+  const int H3 = 3 * (int)F;
+  std::vector<uint> &tri = m.faces;
+  std::vector<int32_t> opp(m.opp.begin(), m.opp.begin() + H3);
+  std::vector<int32_t> vhe(V, -1);
+  std::vector<uint> val(V, 0);
+  for (int h = 0; h < H3; h++) { vhe[tri[h]] = h; val[tri[h]]++; }
+  auto nx = [](int h) { return SimpleTriMesh::next_halfedge(h); };
+  auto pv = [](int h) { return SimpleTriMesh::prev_halfedge(h); };
+  uint64_t rng = seed ? seed : 1;
+  auto rnd = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
+  auto connected = [&](uint c, uint d) {            // is d in the 1-ring of c?  (closed surface: one loop)
+    int h0 = vhe[c], h = h0;
+    do {
+      if (tri[nx(h)] == d) return true;
+      h = nx(opp[h]);
+    } while (h != h0);
+    return false;
+  };
+  std::vector<double> &P = m.points;
+  // min angle (as its cosine's complement: returns the largest cosine) and orientation of triangle
+  // (x, y, z) on the sphere: normal . centroid > 0
+  auto triOk = [&](uint x, uint y, uint z, double cosMax) {
+    const double *px = &P[3 * (size_t)x], *py = &P[3 * (size_t)y], *pz = &P[3 * (size_t)z];
+    double e[3][3];
+    for (int k = 0; k < 3; k++) { e[0][k] = py[k] - px[k]; e[1][k] = pz[k] - py[k]; e[2][k] = px[k] - pz[k]; }
+    const double nrm[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                           e[0][0] * e[1][1] - e[0][1] * e[1][0]};
+    double out = 0;
+    for (int k = 0; k < 3; k++) out += nrm[k] * (px[k] + py[k] + pz[k]);
+    if (!(out > 0)) return false;
+    for (int i = 0; i < 3; i++) {                   // angle between -e[i] and e[(i+1)%3]
+      const double *u = e[i], *w = e[(i + 1) % 3];
+      const double d = -(u[0] * w[0] + u[1] * w[1] + u[2] * w[2]);
+      const double lu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      const double lw = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      if (!(d < cosMax * lu * lw)) return false;
+    }
+    return true;
+  };
+  auto flip = [&](int h, double cosMax) -> bool {   // edge a-b of faces (a,b,c), (b,a,d) becomes c-d
+    const int o = opp[h];
+    const int hn = nx(h), hp = pv(h), on = nx(o), op = pv(o);
+    const uint a = tri[h], b = tri[hn], c = tri[hp], d = tri[op];
+    if (c == d || val[a] <= 3 || val[b] <= 3 || connected(c, d)) return false;
+    if (!triOk(a, d, c, cosMax) || !triOk(b, c, d, cosMax)) return false;   // no folded or needle faces
+    const int e1 = opp[hn], e3 = opp[on];
+    tri[hn] = d; tri[on] = c;                       // f1 = (a, d, c), f2 = (b, c, d)
+    opp[h] = e3; opp[e3] = h;
+    opp[o] = e1; opp[e1] = o;
+    opp[hn] = on; opp[on] = hn;
+    vhe[a] = h; vhe[b] = o; vhe[c] = hp; vhe[d] = op;
+    val[a]--; val[b]--; val[c]++; val[d]++;
+    return true;
+  };
+  // connectivity-only smoothing: every vertex to the centroid of its neighbours, back onto the sphere
+  double R = 0;
+  for (int k = 0; k < 3; k++) R += P[k] * P[k];
+  R = std::sqrt(R);
+  auto smooth = [&](int passes) {
+    std::vector<double> acc(3 * (size_t)V);
+    for (int it = 0; it < passes; it++) {
+      std::fill(acc.begin(), acc.end(), 0.0);
+      for (int h = 0; h < H3; h++) {                // closed surface: each neighbour seen once per vertex
+        const uint a = tri[h], b = tri[nx(h)];
+        for (int k = 0; k < 3; k++) acc[3 * (size_t)a + k] += P[3 * (size_t)b + k];
+      }
+      for (uint v = 0; v < V; v++) {
+        double l = 0;
+        for (int k = 0; k < 3; k++) l += acc[3 * (size_t)v + k] * acc[3 * (size_t)v + k];
+        l = std::sqrt(l);
+        if (l > 0)
+          for (int k = 0; k < 3; k++) P[3 * (size_t)v + k] = acc[3 * (size_t)v + k] * (R / l);
+      }
+    }
+  };
+  const double cos25 = 0.90630778703665, cos8 = 0.99026806874157;
+  const uint64_t nflips = (uint64_t)(flipFraction * 1.5 * (double)F);       // E = 1.5 F
+  for (uint64_t i = 0; i < nflips; i++) flip((int)(rnd() % (uint32_t)H3), cos25);
+  const uint64_t nhigh = (uint64_t)(highValFraction * (double)V);
+  for (uint64_t i = 0; i < nhigh; i++) {
+    const uint v = rnd() % V;
+    // grow v's fan: sweep its ring, flipping each ring edge towards v where the geometry admits it
+    for (int round = 0; round < 4 * highVal && (int)val[v] < highVal; round++) {
+      int h = vhe[v];
+      const int skip = (int)(rnd() % val[v]);
+      for (int k = 0; k < skip; k++) h = nx(opp[h]);
+      bool any = false;
+      for (uint k = 0; k < val[v] && (int)val[v] < highVal; k++) {
+        any |= flip(nx(h), cos8);                   // nx(h) is the edge x-y of face (v, x, y)
+        h = nx(opp[h]);
+      }
+      if (!any) break;
+    }
+  }
+  if (flipFraction > 0 || nhigh > 0) smooth(3);
+  if (noiseAmp > 0)
+    for (uint v = 0; v < V; v++) {
+      const double u = (double)rnd() / 2147483648.0 * 2.0 - 1.0;
+      // radial noise in units of the edge length, so the surface stays a graph over the sphere
+      double r = 0;
+      for (int k = 0; k < 3; k++) r += m.points[3 * (size_t)v + k] * m.points[3 * (size_t)v + k];
+      r = std::sqrt(r);
+      const double sc = 1.0 + noiseAmp * edge * u / r;
+      for (int k = 0; k < 3; k++) m.points[3 * (size_t)v + k] *= sc;
+    }
+  m.H = 0;                                          // tables are stale: rebuild from the faces
+  return FEM_OK;
+}
+
 // nx x ny planar strip tilted 45 degrees in y-z, vertex id = ix*ny + iy, faces
 // (v, v+ny, v+ny+1), (v, v+ny+1, v+1) -- the shape of ResultantPattern.off
 // (ResultantPattern.off:1-4,44,454-457).

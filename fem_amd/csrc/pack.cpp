@@ -221,12 +221,17 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
 //   coef[row_off + w*rows_pad + r]  = (w, Cx, Cy, Cz) of entry w of local row r (r < m[k-1])
 //   idx2[row_off/2 + (w/2)*rows_pad + r] = local ids of entries w, w+1 of row r, 16 bits each
 // (padding entries: own local id, coef 0).  rows_pad = m[k-1] rounded up to 64; row_off is even.
+// Rows with more than W entries (irregular meshes) keep their first W in the register tile; the
+// rest ("extras", in row order) follow the tile's block: coef/topo[row_off + W*rows_pad + e], and
+//   xinfo[meta[14] + r]            = first extra of row r | count << 16          (r < rows_pad)
+//   xinfo[meta[14] + rows_pad + e] = local column id of extra e                  (e < meta[15])
+// meta[14], meta[15] = xinfo offset, number of extras; tiles without extras have no xinfo block.
+// A tile holds at most maxExtra extras and a row at most 65535 of them.
 int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ranges, int ksteps, uint T, uint R,
-                   uint W, uint maxLocal, TileLayout &o) {
-  if (ksteps < 1 || ksteps > 8 || (W & 1) || W == 0 || T == 0 || R == 0 || maxLocal > 65535) return FEM_ERR_INVALID;
+                   uint W, uint maxLocal, uint maxExtra, TileLayout &o) {
+  if (ksteps < 1 || ksteps > 8 || (W & 1) || W == 0 || T == 0 || R == 0 || maxLocal > 65535 || maxExtra > 65535)
+    return FEM_ERR_INVALID;
   const uint V = op.V;
-  for (uint v = 0; v < V; v++)
-    if (op.rowptr[v + 1] - op.rowptr[v] > W) return FEM_ERR_LIMIT;      // row wider than the register tile
   o = TileLayout();
   o.ksteps = ksteps; o.T = T; o.R = R; o.W = W;
   std::vector<std::pair<uint, uint>> work(ranges.rbegin(), ranges.rend());
@@ -261,6 +266,15 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
       if (!fits) break;
     }
     if (ksteps == 1 && m[0] > T * R) fits = false;
+    uint xcount = 0;
+    if (fits) {
+      const uint rowsIn = m[ksteps - 1];
+      for (uint r = 0; r < rowsIn; r++) {
+        const uint d = op.rowptr[local[r] + 1] - op.rowptr[local[r]];
+        if (d > W) xcount += d - W;
+      }
+      if (xcount > maxExtra) fits = false;
+    }
     tileNo++;
     if (tileNo == 0xffffffffu) return FEM_ERR_LIMIT;
     if (!fits) {
@@ -273,34 +287,49 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
     for (uint i = 0; i < local.size(); i++) locId[local[i]] = i;
     const uint rows = m[ksteps - 1], rowsPad = (rows + 63) / 64 * 64;
     const size_t rowOff = o.coef.size() / 4;
-    if (rowOff + (size_t)W * rowsPad > 0xffffffffull) return FEM_ERR_LIMIT;
+    const size_t blockEntries = (size_t)W * rowsPad + (xcount + 1) / 2 * 2;
+    if (rowOff + blockEntries > 0xffffffffull || o.xinfo.size() + rowsPad + xcount > 0xffffffffull) return FEM_ERR_LIMIT;
     uint meta[16] = {b, (uint)o.ghost.size(), (uint)rowOff, rowsPad, (uint)ksteps};
     for (int j = 0; j <= ksteps; j++) meta[5 + j] = m[j];
+    const size_t xOff = o.xinfo.size();
+    meta[14] = (uint)xOff; meta[15] = xcount;
     o.meta.insert(o.meta.end(), meta, meta + 16);
     o.ghost.insert(o.ghost.end(), local.begin() + m[0], local.end());
-    o.coef.resize(4 * (rowOff + (size_t)W * rowsPad), 0.0);
-    o.topo.resize(2 * (rowOff + (size_t)W * rowsPad), 0xffffffffu);
-    o.idx2.resize((rowOff + (size_t)W * rowsPad) / 2, 0u);
+    o.coef.resize(4 * (rowOff + blockEntries), 0.0);
+    o.topo.resize(2 * (rowOff + blockEntries), 0xffffffffu);
+    o.idx2.resize((rowOff + blockEntries) / 2, 0u);
+    if (xcount) o.xinfo.resize(xOff + rowsPad + xcount, 0u);
+    uint xnext = 0;
     for (uint r = 0; r < rowsPad; r++) {
       uint ids[16];
       for (uint w = 0; w < W; w++) ids[w] = r < rows ? r : 0;
       if (r < rows) {
         const uint v = local[r];
         uint w = 0;
+        const uint xfirst = xnext;
         for (uint q = op.rowptr[v]; q < op.rowptr[v + 1]; q++, w++) {
-          ids[w] = locId[op.col[q]];
-          const size_t pos = rowOff + (size_t)w * rowsPad + r;
+          size_t pos;
+          if (w < W) {
+            ids[w] = locId[op.col[q]];
+            pos = rowOff + (size_t)w * rowsPad + r;
+          } else {
+            o.xinfo[xOff + rowsPad + xnext] = locId[op.col[q]];
+            pos = rowOff + (size_t)W * rowsPad + xnext++;
+          }
           o.topo[2 * pos] = op.f1[q]; o.topo[2 * pos + 1] = op.f2[q];
           for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)q + d];
         }
+        if (xnext > xfirst) o.xinfo[xOff + r] = xfirst | ((xnext - xfirst) << 16);
       }
       for (uint w = 0; w < W; w += 2) o.idx2[rowOff / 2 + (size_t)(w / 2) * rowsPad + r] = ids[w] | (ids[w + 1] << 16);
     }
     o.maxLocal = std::max(o.maxLocal, m[ksteps]);
+    o.maxExtra = std::max(o.maxExtra, xcount);
     o.ntiles++;
     o.rowSteps += rows;
   }
   o.ghost.push_back(0);            // pad: the kernel reads ghost[goff] even for tiles without rings
+  o.xinfo.push_back(0);
   return FEM_OK;
 }
 

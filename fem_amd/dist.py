@@ -11,16 +11,25 @@ import fem_amd as fa
 _PROFILES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
+def _time_step(om, model, rule):
+    """"reference": dt = 0.1 maxEdgeLen^2 (main.cpp:188; assumes near-uniform triangles);
+    "stable": inside the explicit diffusion limit of the assembled operator (irregular meshes)"""
+    st = om.stats()
+    if rule == "stable":
+        return 0.2 / (max(1.0, model.D) * float(np.abs(st["wVtx"]).max()))
+    return 0.1 * st["maxEdgeLen"] ** 2
+
+
 class SingleRun:
     """partition -> reorder -> assemble (host, once) -> native plan; seeded IC of main.cpp:178-186"""
-    def __init__(self, mesh, nparts, precision="f32", seed=1, ksteps=0):
+    def __init__(self, mesh, nparts, precision="f32", seed=1, ksteps=0, dt_rule="reference"):
         self.ksteps = ksteps
         self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
         self.part = mesh.partition(nparts)
         om = self.part.ordered
         om.init_stats(fa.PREC_F64)
-        self.dt = 0.1 * om.stats()["maxEdgeLen"] ** 2          # main.cpp:188
         self.model = fa.default_model()
+        self.dt = _time_step(om, self.model, dt_rule)
         self.precision = precision
         self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, part=self.part, ksteps=ksteps)
         n0, c0 = fa.initial_condition(om.V, seed)
@@ -109,15 +118,15 @@ class ShardedRun:
     """the mesh split along the partition ranges over `world` ranks; k ghost rings let every rank
     take k steps between two halo exchanges (communication-avoiding explicit stepping)"""
     def __init__(self, mesh, nparts, rank, world, precision="f32", seed=1, krings=None, make_stepper=None,
-                 ksteps=0):
+                 ksteps=0, dt_rule="reference"):
         self.ksteps = ksteps
         self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
         self.steps_per_launch = max(1, ksteps)
         self.part = mesh.partition(nparts)
         om = self.part.ordered
         om.init_stats(fa.PREC_F64)
-        self.dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
         self.model = fa.default_model()
+        self.dt = _time_step(om, self.model, dt_rule)
         self.precision = precision
         self.krings = krings or int(os.environ.get("FEM_HALO_RINGS", "8"))
         self.shard = fa.Shard(self.part, rank, world, self.krings)

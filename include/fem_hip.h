@@ -101,6 +101,12 @@ int fem_off_write(const char *path, int V, int F, const double *points, const fe
  * h=0.1 reproduces its geometry). */
 int fem_make_icosphere(int nu, double edge, int *V, int *F, double **points, fem_uint **tri);
 int fem_make_strip(int nx, int ny, double h, int *V, int *F, double **points, fem_uint **tri);
+/* "scanned-like" irregular closed surface for BASELINE config 4 (no scan data is available):
+ * the icosphere with flip_fraction * E seeded random edge flips, high_valence_fraction * V vertices
+ * driven to valence >= high_valence by fans of flips, and radial noise of noise_amp edge lengths */
+int fem_make_scanned_like(int nu, double edge, fem_uint seed, double flip_fraction, double noise_amp,
+                          double high_valence_fraction, int high_valence, int *V, int *F,
+                          double **points, fem_uint **tri);
 
 /* Initial condition of initializeData, main.cpp:178-186, with rand() replaced
  * by an explicit Lehmer generator (x <- 48271 x mod 2^31-1) seeded by `seed`. */

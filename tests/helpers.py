@@ -52,3 +52,15 @@ def sphere_case(nu=8, nparts=4, **kw):
 def strip_case(nparts=3, **kw):
     pts, tri = fa.make_strip(11, 41, 0.1)
     return Case(pts, tri, nparts, **kw)
+
+
+def scan_case(nu=24, nparts=8, mesh_seed=3, **kw):
+    """irregular "scanned-like" surface (BASELINE config 4 stand-in): valences 3..16"""
+    pts, tri = fa.make_scanned_like(nu, 0.1, seed=mesh_seed, high_valence_fraction=0.01)
+    return Case(pts, tri, nparts, **kw)
+
+
+def stable_dt(stats, model, safety=0.2):
+    """explicit-Euler step well inside the diffusion limit of an irregular mesh (the reference's
+    dt = 0.1 maxEdgeLen^2 assumes near-uniform triangles)"""
+    return safety / (max(1.0, model.D) * np.abs(np.asarray(stats.wVtx)).max())

@@ -8,7 +8,7 @@ import pytest
 
 import fem_amd as fa
 import oracle_lib as ol
-from helpers import Case, rel_l2, sphere_case, strip_case
+from helpers import Case, rel_l2, scan_case, sphere_case, strip_case
 
 pytestmark = pytest.mark.gpu
 
@@ -25,7 +25,8 @@ def check_records(rec, st, F, tol):
     assert abs(rec[:, 7].max() - st.maxEdgeLen) <= tol * st.maxEdgeLen
 
 
-@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(12, n), 6), (lambda n: strip_case(n), 3)])
+@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(12, n), 6), (lambda n: strip_case(n), 3),
+                                         (lambda n: scan_case(16, n), 5)])
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 @pytest.mark.parametrize("ksteps", [0, 4])
 def test_device_assembly_matches_oracle(make, nparts, prec, ksteps):

@@ -14,7 +14,7 @@ import pytest
 
 import fem_amd as fa
 import oracle_lib as ol
-from helpers import rel_l2, smooth_ic, sphere_case, strip_case
+from helpers import rel_l2, scan_case, smooth_ic, sphere_case, stable_dt, strip_case
 
 pytestmark = pytest.mark.gpu
 
@@ -230,3 +230,73 @@ def test_fused_tile_plan_f32_matches_single_step_plan():
     n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
     n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
     assert rel_l2(outs[0][0], n_ref) <= TOL_F32 and rel_l2(outs[0][1], c_ref) <= TOL_F32
+
+
+def test_irregular_mesh_all_paths():
+    """BASELINE config 4 shape (irregular valences 3..16, thin triangles, negative cotangent
+    weights): the drop-in `step`, the sliced-ELL plan and the fused plan (rows wider than the
+    register tile go through the LDS overflow entries) against the oracle"""
+    case = scan_case(24, 8)
+    deg = np.diff(case.topo.rowptr)
+    assert deg.max() >= 12 and deg.min() <= 4
+    st = case.ostats(ol.F64)
+    dt = stable_dt(st, case.model)
+    n0, c0 = smooth_ic(case.pts)
+    marr = case.model.as_array()
+    # reference symbol on the reference layout (mixed precision)
+    case.mesh.init_stats(fa.PREC_MIXED)
+    dev = _ref_device(case)
+    dev.set_state(n0, c0)
+    dev.run(10, dt, case.model)
+    n_gpu, c_gpu = dev.get_state()
+    n_ref, c_ref = case.ostats(ol.MIXED).step(n0, c0, dt, 10, marr)
+    assert rel_l2(n_gpu, n_ref) <= TOL_REF and rel_l2(c_gpu, c_ref) <= TOL_REF
+    # native plans, fp64
+    case.mesh.init_stats(fa.PREC_F64)
+    n_ref, c_ref = st.step(n0, c0, dt, 22, marr)
+    outs = {}
+    for ksteps in (0, 1, 4):
+        plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+        plan.set_state(n0, c0)
+        plan.run(22, dt, case.model)
+        outs[ksteps] = plan.get_state()
+        assert rel_l2(outs[ksteps][0], n_ref) <= TOL_F64 and rel_l2(outs[ksteps][1], c_ref) <= TOL_F64
+    # same accumulation order in both kernels: bit-identical results
+    assert np.array_equal(outs[0][0], outs[4][0]) and np.array_equal(outs[0][1], outs[4][1])
+    # fp32
+    n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+    n_ref, c_ref = st.step(n0r, c0r, dt, 100, marr)
+    for ksteps in (0, 4):
+        plan = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps)
+        plan.set_state(n0, c0)
+        plan.run(100, dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        assert rel_l2(n_gpu, n_ref) <= TOL_F32 and rel_l2(c_gpu, c_ref) <= TOL_F32
+
+
+def test_irregular_mesh_small_tiles_and_sharded_plan():
+    """many overflow entries per tile (5 % of the vertices fanned to valence 16), partitions that
+    must be split, and a shard's plan (ghost rows in their own tiles)"""
+    from helpers import Case
+    pts, tri = fa.make_scanned_like(20, 0.1, seed=9, flip_fraction=0.3, high_valence_fraction=0.05)
+    case = Case(pts, tri, 3)
+    case.mesh.init_stats(fa.PREC_F64)
+    st = case.ostats(ol.F64)
+    dt = stable_dt(st, case.model)
+    n_ref, c_ref = st.step(case.n0, case.c0, dt, 9, case.model.as_array())
+    plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=3)
+    plan.set_state(case.n0, case.c0)
+    plan.run(9, dt, case.model)
+    n_gpu, c_gpu = plan.get_state()
+    assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+    # shard 1 of 3 with 3 ghost rings: 3 steps without exchange are exact on the owned rows
+    shard = fa.Shard(case.part, 1, 3, 3)
+    l2g = shard.loc2glob
+    n3, c3 = st.step(case.n0, case.c0, dt, 3, case.model.as_array())
+    for ksteps in (0, 3):
+        sp = fa.Plan(case.mesh, fa.PREC_F64, shard=shard, part=case.part, ksteps=ksteps)
+        sp.set_state(case.n0[l2g], case.c0[l2g])
+        sp.run(3, dt, case.model)
+        ns, cs = sp.get_state()
+        own = slice(0, shard.n_own)
+        assert rel_l2(ns[own], n3[l2g[own]]) <= TOL_F64 and rel_l2(cs[own], c3[l2g[own]]) <= TOL_F64

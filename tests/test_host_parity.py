@@ -182,3 +182,38 @@ def test_icosphere_generator():
         assert vol > 0
         e = np.linalg.norm(pts[tri[:, 0]] - pts[tri[:, 1]], axis=1)
         assert 0.8 < e.mean() / 0.1 < 1.2
+
+
+def test_scanned_like_generator():
+    """BASELINE config 4 stand-in: irregular valences incl. local high-valence fans, still a closed
+    oriented 2-manifold with usable triangles; seeded (same seed -> same mesh)."""
+    pts, tri = fa.make_scanned_like(40, 0.1, seed=5)
+    p2, t2 = fa.make_scanned_like(40, 0.1, seed=5)
+    assert np.array_equal(pts, p2) and np.array_equal(tri, t2)
+    p3, t3 = fa.make_scanned_like(40, 0.1, seed=6)
+    assert not np.array_equal(tri, t3)
+    V, F = len(pts), len(tri)
+    assert V == 10 * 40 * 40 + 2 and F == 20 * 40 * 40
+    m = fa.Mesh(pts, tri)                                   # raises if a directed edge repeats (non-manifold)
+    topo = m.topology()
+    assert m.H == 3 * F                                     # closed: no boundary half-edges
+    deg = np.diff(topo["rowptr"])
+    assert deg.min() >= 3 and deg.max() >= 10 and (deg > 6).mean() > 0.1 and (deg < 6).mean() > 0.1
+    assert V - 3 * F // 2 + F == 2
+    vol = np.einsum("ij,ij->i", pts[tri[:, 0]], np.cross(pts[tri[:, 1]], pts[tri[:, 2]])).sum() / 6
+    r = np.linalg.norm(pts, axis=1)
+    assert vol > 0.9 * 4 / 3 * np.pi * r.min() ** 3
+    s = m.init_stats(fa.PREC_F64).stats()
+    ang = np.degrees(s["meshAngle"][:3 * F])
+    assert ang.min() > 5 and ang.max() < 165
+    assert s["areaPerVtx"].min() > 0 and np.isfinite(s["wHej"]).all()
+    # the oracle's topology agrees on the irregular mesh too
+    t = ol.Topology(V, tri)
+    for k in ("opp", "rowptr", "col", "row_he"):
+        assert np.array_equal(topo[k], getattr(t, k)), k
+    # flips/fans/noise off = the plain geodesic sphere
+    p0, t0 = fa.make_scanned_like(7, 0.1, seed=1, flip_fraction=0, noise_amp=0, high_valence_fraction=0)
+    pi, ti = fa.make_icosphere(7, 0.1)
+    assert np.array_equal(t0, ti) and np.array_equal(p0, pi)
+    with pytest.raises(fa.FemError):
+        fa.make_scanned_like(7, 0.1, seed=1, noise_amp=0.7)
