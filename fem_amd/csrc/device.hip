@@ -728,10 +728,12 @@ void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_wei
           double dt, fem_uint smem_size) {
   (void)threads;
   // the reference caller sizes smem as 32 B per vertex of the largest partition (main.cpp:369)
-  (void)fem_step(fn_src, fn_dst, fv, fv_weights, fv_pitchInBytes, fvw_pitchInBytes, nbr, vtxW,
-                 vw_pitchInBytes, vertex_weights, vv_pitchInBytes, vws_pitchInBytes, vv_size, grads,
-                 he_pitchInBytes, parts_n, block_face_count, blocks, dt, (smem_size + 31) / 32, nullptr,
-                 nullptr);
+  const int rc = fem_step(fn_src, fn_dst, fv, fv_weights, fv_pitchInBytes, fvw_pitchInBytes, nbr, vtxW,
+                          vw_pitchInBytes, vertex_weights, vv_pitchInBytes, vws_pitchInBytes, vv_size, grads,
+                          he_pitchInBytes, parts_n, block_face_count, blocks, dt, (smem_size + 31) / 32, nullptr,
+                          nullptr);
+  // void like the reference's: fem_last_error() right after the call is THIS call's status
+  if (rc == FEM_OK) { fem::g_last_error = FEM_OK; fem::g_error_detail.clear(); }
 }
 
 // ---- reference device harness (GPUrun, main.cpp:344-452) -------------------

@@ -60,7 +60,8 @@ void fem_free(void *p);      /* frees arrays returned through T** out-params */
  * cudaMallocPitch/cudaMalloc3D returned them, blocks = number of partitions.
  * `threads` and `smem_size` are accepted and ignored (the kernel picks its
  * own wave64 geometry).  Asynchronous on the default stream; constants =
- * fem_default_model().  Errors: fem_last_error(). */
+ * fem_default_model().  Errors: fem_last_error() right after the call is this
+ * call's status (a successful step() resets it to FEM_OK). */
 void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
           fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
           fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
