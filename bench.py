@@ -149,6 +149,7 @@ def main():
         kernel_ms = dev_ms / launches                       # average launch duration, device events
         v_per_launch = runner.vertices_per_launch           # owned vertices this rank advances per launch
         achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch * (args.steps / launches) / (kernel_ms * 1e-3) / 1e9
+        traffic = runner.measured_traffic()
         out = {
             "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -163,7 +164,9 @@ def main():
                        "halo_rings": getattr(runner, "krings", None),
                        "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": runner.measured_traffic(),
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_rate": traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None,
+                         "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                          "alg_bytes_per_vertex_step": ALG_BYTES_PER_VERTEX_STEP, "avg_launch_ms": kernel_ms,
                          "time_steps_per_launch": args.steps / launches,
                          "layout_bytes_per_launch": runner.layout_bytes_per_launch},

@@ -595,7 +595,7 @@ constexpr int kTileW = 6;
 constexpr fem_uint kTileMaxLocal = 4096;
 constexpr fem_uint kTileMaxExtra = 1536;  // LDS-resident overflow entries per tile (rows with more than kTileW neighbours)
 struct TileCfg { int tpb, r, minw; };
-constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}};
+constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}, {1024, 2, 4}};
 constexpr int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
 
 
@@ -668,7 +668,7 @@ static hipError_t launchTile(fem_plan *p, const void *src, void *dst, int nsteps
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
-  constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : (TPB == 512 ? 2 : 1);
+  constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : (TPB == 1024 ? 4 : (TPB == 512 ? 2 : 1));
   auto kern = p->maxExtra ? tile_step_kernel<T, TPB, R, kTileW, MINW, true> : tile_step_kernel<T, TPB, R, kTileW, MINW, false>;
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4);
   if (lds > 64 * 1024) {
@@ -1023,7 +1023,7 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
     e = p->precision == FEM_PREC_F32 ? launchTile<float, C>(p, src, dst, c, mf, (hipStream_t)stream) \
                                      : launchTile<double, C>(p, src, dst, c, md, (hipStream_t)stream); \
     break;
-      switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) }
+      switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) FEM_TILE_CASE(5) }
 #undef FEM_TILE_CASE
       if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "tile_step_kernel launch", e);
       p->cur ^= 1;
