@@ -324,16 +324,20 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
 
 // ---------------------------------------------------------------------------
 // Device assembly (initMeshStats on the GPU; reference src/mesh_function.cpp:70-397).
-//   assemble_faces_kernel : one thread per element.  Coalesced SoA connectivity loads, three
-//     position gathers (16-B records), then everything the reference derives per face/half-edge:
-//     corner angles + cotangents (A1, :70-160), area (A2, :162-216), longest edge (A4, :310-350),
-//     hat-function gradients gradVec12/13 (A5, :351-397).  One 64-B record per face:
-//     {ang_a, ang_b, ang_c, area | cot_a, cot_b, cot_c, maxEdge | g12.xyz, 0 | g13.xyz, 0}.
-//   assemble_rows_*_kernel : one thread per operator row; the row's entries name the faces left
-//     and right of each edge (pack.cpp), so the lumped mass (sum of area/3), the angle sum and
-//     the per-edge cotangent sums (A3, :219-271) are per-row sequential reductions over those
-//     records -- a segmented reduction with the segments fixed by the layout: no atomics,
-//     bit-reproducible.  Writes (w, Cx, Cy, Cz) straight into the plan's operator array.
+//   assemble_rows_*_kernel : one thread per operator row, straight from the vertex positions:
+//     each entry names its neighbour and the two vertices opposite the edge (pack.cpp), so the
+//     thread rebuilds the (at most two) faces on the edge, and the faces left of the row's
+//     outgoing edges are all faces around the vertex once: lumped mass (sum of area/3), angle
+//     sum, cotangent sums (A3, :219-271), angle-weighted hat gradients and the longest edge (A4)
+//     are per-row sequential sums with the order fixed by the layout -- no atomics, no per-face
+//     intermediate in HBM, bit-reproducible.  Writes (w, Cx, Cy, Cz) straight into the plan's
+//     operator array.  Every face is recomputed by the rows that touch it (ALU is free here: the
+//     kernel moves 16 B table + 16 B result per entry and gathers positions from L2).
+//   assemble_faces_kernel : one thread per element, the reference's per-face/half-edge arrays
+//     (A1 angles + cotangents :70-160, A2 area :162-216, A4 longest edge :310-350, A5 gradVec12/13
+//     :351-397) as one 64-B record per face
+//     {ang_a, ang_b, ang_c, area | cot_a, cot_b, cot_c, maxEdge | g12.xyz, 0 | g13.xyz, 0};
+//     only run for fem_plan_face_records (checks, output), not needed by the operator.
 // ---------------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ T dev_acos(T x);
 template <> __device__ __forceinline__ float dev_acos<float>(float x) { return acosf(x); }
@@ -344,6 +348,9 @@ template <> __device__ __forceinline__ double dev_tan<double>(double x) { return
 template <typename T> __device__ __forceinline__ T dev_sqrt(T x);
 template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return sqrtf(x); }
 template <> __device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T dev_rsqrt(T x);
+template <> __device__ __forceinline__ float dev_rsqrt<float>(float x) { return __frsqrt_rn(x); }   // v_rsq_f32, 1 ulp
+template <> __device__ __forceinline__ double dev_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
 
 template <typename T>
 __device__ __forceinline__ void corner_angle(const T *p1, const T *p2, const T *p3, T &ang, T &cot) {
@@ -420,86 +427,158 @@ __global__ __launch_bounds__(1024) void max_reduce_kernel(const double *__restri
 }
 
 constexpr int kTileWDev = 6;       // entries per row of the tile layout (= kTileW)
-template <typename T> __device__ __forceinline__ T comp(const typename Vec<T>::t4 &v, uint k) {
-  return k == 0 ? v.x : (k == 1 ? v.y : v.z);
+
+// One corner of the fan around v: face (v, p, q), counter-clockwise, e1 = p - v, e2 = q - v.
+//   c = e1 x e2 (|c| = 2 area), angle at v = acos(e1.e2 / (|e1||e2|)),
+//   cot at q = (|e2|^2 - e1.e2) / |c|, cot at p = (|e1|^2 - e1.e2) / |c|,
+//   grad phi_p = e2 x c / |c|^2, grad phi_q = c x e1 / |c|^2
+// (hat gradient = normal x opposite edge / 2 area).  Same quantities as mesh_function.cpp:70-397
+// (A1 angles/cotangents, A2 areas, A5 gradVec12/13), per row instead of per face.
+template <typename T> struct FanFace { T cx, cy, cz, c2, d, l1, l2; };
+template <typename T>
+__device__ __forceinline__ FanFace<T> fan_face(const T *e1, const T *e2) {
+  FanFace<T> f;
+  f.cx = e1[1] * e2[2] - e1[2] * e2[1]; f.cy = e1[2] * e2[0] - e1[0] * e2[2]; f.cz = e1[0] * e2[1] - e1[1] * e2[0];
+  f.c2 = f.cx * f.cx + f.cy * f.cy + f.cz * f.cz;
+  f.d = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+  f.l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+  f.l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+  return f;
 }
 
-// One operator row: entries e(k) = first + k * stride, k < width <= W.  Fully unrolled over W so
-// that each phase issues all of its loads before the first use: 2W table words, then W records for
-// the lumped mass / angle sum, then the 2W x 4 record quarters of the edge terms.
-// Entries k >= SPLIT (the tile layout's extras of a wide row) live at xfirst + (k - SPLIT).
+// One operator row straight from the positions: entries e(k) = first + k * stride for k < SPLIT,
+// xfirst + (k - SPLIT) beyond (the tile layout's extras of a wide row), k < width <= W.
+// Per entry (v -> j): face (v, j, o1) on the left and (v, o2, j) on the right give the cotangents
+// opposite the edge (A3, mesh_function.cpp:219-271) and the angle-weighted hat gradients of j
+// (mesh_function.h:35-110); the faces left of v's outgoing half-edges are all faces around v once,
+// so the lumped mass and the angle sum are row sums of the same quantities.  Returns the longest
+// edge at v (A4, :310-350).
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t4 entry_terms(const typename Vec<T>::t4 *__restrict__ pos,
+                                                           const typename Vec<T>::t4 &P, uint vg, const uint4 &t, T &area3,
+                                                           T &theta, T &maxe2) {
+  typedef typename Vec<T>::t4 T4;
+  const bool real = t.w != 0u, has1 = real && t.y != ~0u, has2 = real && t.z != ~0u;
+  const T4 J = pos[real ? t.x : vg], O1 = pos[has1 ? t.y : vg], O2 = pos[has2 ? t.z : vg];
+  const T ej[3] = {J.x - P.x, J.y - P.y, J.z - P.z};
+  const T e1[3] = {O1.x - P.x, O1.y - P.y, O1.z - P.z};
+  const T e2[3] = {O2.x - P.x, O2.y - P.y, O2.z - P.z};
+  T4 a;
+  a.x = a.y = a.z = a.w = 0;
+  if (has1) {                                          // face (v, j, o1): p = j, q = o1
+    const FanFace<T> f = fan_face<T>(ej, e1);
+    const T rcn = dev_rsqrt(f.c2);                     // 1 / |c|
+    const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
+    a.x += (f.l2 - f.d) * rcn;                         // cot at o1
+    const T s = ang * rcn * rcn;                       // angle * grad phi_j, grad phi_p = e2 x c / |c|^2
+    a.y += s * (e1[1] * f.cz - e1[2] * f.cy); a.z += s * (e1[2] * f.cx - e1[0] * f.cz); a.w += s * (e1[0] * f.cy - e1[1] * f.cx);
+    theta += ang; area3 += f.c2 * rcn / 6;             // area / 3 = |c| / 6
+  }
+  if (has2) {                                          // face (v, o2, j): p = o2, q = j
+    const FanFace<T> f = fan_face<T>(e2, ej);
+    const T rcn = dev_rsqrt(f.c2);
+    const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
+    a.x += (f.l1 - f.d) * rcn;                         // cot at o2
+    const T s = ang * rcn * rcn;                       // grad phi_q = c x e1 / |c|^2
+    a.y += s * (f.cy * e2[2] - f.cz * e2[1]); a.z += s * (f.cz * e2[0] - f.cx * e2[2]); a.w += s * (f.cx * e2[1] - f.cy * e2[0]);
+  }
+  if (real) maxe2 = fmax(maxe2, ej[0] * ej[0] + ej[1] * ej[1] + ej[2] * ej[2]);
+  return a;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t4 entry_scale(const typename Vec<T>::t4 &a, T area3, T theta) {
+  typename Vec<T>::t4 o;
+  o.x = area3 > 0 ? a.x / (2 * area3) : (T)0;
+  if (theta > 0) { o.y = a.y / theta; o.z = a.z / theta; o.w = a.w / theta; } else { o.y = o.z = o.w = 0; }
+  return o;
+}
+
+// W <= 12: fully unrolled, unnormalised terms in registers.  W = 0: any width, a plain loop that
+// parks the unnormalised terms in the output array and rescales them in a second sweep.
 template <typename T, int W, int SPLIT = W>
-__device__ __forceinline__ void assemble_row(const typename Vec<T>::t4 *__restrict__ rec, const uint *__restrict__ topo,
-                                             typename Vec<T>::t4 *__restrict__ coef, size_t first, size_t stride, uint width,
-                                             size_t xfirst = 0) {
+__device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
+                                          typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
+                                          uint width, size_t xfirst = 0) {
   typedef typename Vec<T>::t4 T4;
   auto at = [&](int k) { return k < SPLIT ? first + k * stride : xfirst + (size_t)(k - SPLIT); };
-  uint t1[W], t2[W];
+  const T4 P = pos[vg];
+  T area3 = 0, theta = 0, maxe2 = 0;
+  if constexpr (W > 0) {
+    uint4 t[W];
 #pragma unroll
-  for (int k = 0; k < W; k++) {
-    const uint2 t = (uint)k < width ? *reinterpret_cast<const uint2 *>(topo + 2 * at(k)) : make_uint2(~0u, ~0u);
-    t1[k] = t.x; t2[k] = t.y;
+    for (int k = 0; k < W; k++) t[k] = (uint)k < width ? topo[at(k)] : make_uint4(0u, ~0u, ~0u, 0u);
+    T4 acc[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) acc[k] = entry_terms<T>(pos, P, vg, t[k], area3, theta, maxe2);
+#pragma unroll
+    for (int k = 0; k < W; k++)
+      if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], area3, theta);
+  } else {
+    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_terms<T>(pos, P, vg, topo[at(k)], area3, theta, maxe2);
+    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_scale<T>(coef[at(k)], area3, theta);
   }
-  T4 q0[W];
-#pragma unroll
-  for (int k = 0; k < W; k++) q0[k] = rec[4 * (size_t)(t1[k] == ~0u ? 0 : t1[k] >> 2)];
-  T area3 = 0, theta = 0;
-#pragma unroll
-  for (int k = 0; k < W; k++)
-    if (t1[k] != ~0u) { theta += comp<T>(q0[k], t1[k] & 3u); area3 += q0[k].w / 3; }
-#pragma unroll
-  for (int k = 0; k < W; k++) {
-    T w = 0, cx = 0, cy = 0, cz = 0;
-#pragma unroll
-    for (int side = 0; side < 2; side++) {
-      const uint t = side == 0 ? t1[k] : t2[k];
-      const size_t f = t == ~0u ? 0 : t >> 2;
-      const uint cv = t & 3u;
-      const uint cj = side == 0 ? (cv + 1) % 3 : (cv + 2) % 3;       // corner of the neighbour j
-      const uint co = 3 - cv - cj;                                    // corner opposite the edge (v, j)
-      const T4 r0 = side == 0 ? q0[k] : rec[4 * f], r1 = rec[4 * f + 1], g12 = rec[4 * f + 2], g13 = rec[4 * f + 3];
-      if (t == ~0u) continue;
-      w += comp<T>(r1, co);
-      const T a = comp<T>(r0, cv);
-      const T gx = cj == 0 ? g12.x : (cj == 1 ? g13.x : -(g12.x + g13.x));
-      const T gy = cj == 0 ? g12.y : (cj == 1 ? g13.y : -(g12.y + g13.y));
-      const T gz = cj == 0 ? g12.z : (cj == 1 ? g13.z : -(g12.z + g13.z));
-      cx += a * gx; cy += a * gy; cz += a * gz;
-    }
-    T4 o;
-    o.x = area3 > 0 ? w / (2 * area3) : (T)0;
-    if (theta > 0) { o.y = cx / theta; o.z = cy / theta; o.w = cz / theta; } else { o.y = o.z = o.w = 0; }
-    if (t1[k] == ~0u && t2[k] == ~0u) { o.x = o.y = o.z = o.w = 0; }
-    if ((uint)k < width) coef[at(k)] = o;
-  }
+  return dev_sqrt(maxe2);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ rec,
-                                                                 const uint *__restrict__ topo, const uint *__restrict__ slice_off,
-                                                                 typename Vec<T>::t4 *__restrict__ coef, uint nslices) {
+__device__ __forceinline__ T assemble_row_wide(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
+                                               typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
+                                               uint width, size_t xfirst) {
+  return assemble_row<T, 0, kTileWDev>(pos, topo, coef, vg, first, stride, width, xfirst);
+}
+
+// longest edge: wave shuffle reduction, one partial per workgroup (max_reduce_kernel finishes it)
+__device__ __forceinline__ void block_max_256(double m, double *__restrict__ blockMax) {
+  __shared__ double s_part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ slice_off,
+                                                                 const uint *__restrict__ rowg,
+                                                                 typename Vec<T>::t4 *__restrict__ coef, uint nslices, uint V,
+                                                                 double *__restrict__ blockMax) {
   const uint slice = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-  if (slice >= nslices) return;
-  const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
-  if (width <= 6) assemble_row<T, 6>(rec, topo, coef, (size_t)off + lane, 64, width);
-  else if (width <= 12) assemble_row<T, 12>(rec, topo, coef, (size_t)off + lane, 64, width);
-  else assemble_row<T, 32>(rec, topo, coef, (size_t)off + lane, 64, width < 32 ? width : 32);   // valence <= 32
+  T me = 0;
+  if (slice < nslices) {
+    const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
+    const uint row = min(slice * 64 + lane, V - 1);    // rows >= V: padding entries only (flag 0)
+    const uint vg = rowg[row];
+    if (width <= 6) me = assemble_row<T, 6>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
+    else if (width <= 12) me = assemble_row<T, 12>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
+    else me = assemble_row<T, 0, (1 << 30)>(pos, topo, coef, vg, (size_t)off + lane, 64, width);   // no split: all entries strided
+  }
+  block_max_256((double)me, blockMax);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ rec,
-                                                                 const uint *__restrict__ topo, const uint *__restrict__ meta,
-                                                                 const uint *__restrict__ xinfo,
-                                                                 typename Vec<T>::t4 *__restrict__ coef, uint W) {
+__global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ meta,
+                                                                 const uint *__restrict__ ghost, const uint *__restrict__ xinfo,
+                                                                 const uint *__restrict__ rowg,
+                                                                 typename Vec<T>::t4 *__restrict__ coef, uint W,
+                                                                 double *__restrict__ blockMax) {
   const uint *mt = meta + 16 * (size_t)blockIdx.x;
-  const uint roff = mt[2], rpad = mt[3], rows = mt[5 + mt[4] - 1], xoff = mt[14], xcnt = mt[15];
+  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], n0 = mt[5], rows = mt[5 + mt[4] - 1];
+  const uint xoff = mt[14], xcnt = mt[15];
+  T me = 0;
   for (uint r = threadIdx.x; r < rows; r += blockDim.x) {
+    const uint vg = rowg[r < n0 ? base + r : ghost[goff + (r - n0)]];
     const uint xi = xcnt ? xinfo[xoff + r] : 0u, nx = xi >> 16;
     const size_t first = (size_t)roff + r, xfirst = (size_t)roff + (size_t)W * rpad + (xi & 0xffffu);
-    if (nx == 0) assemble_row<T, kTileWDev>(rec, topo, coef, first, rpad, W);
-    else if (nx <= 6) assemble_row<T, 12, kTileWDev>(rec, topo, coef, first, rpad, W + nx, xfirst);
-    else assemble_row<T, 32, kTileWDev>(rec, topo, coef, first, rpad, W + (nx < 26 ? nx : 26), xfirst);   // valence <= 32
+    T e;
+    if (nx == 0) e = assemble_row<T, kTileWDev>(pos, topo, coef, vg, first, rpad, W);
+    else if (nx <= 6) e = assemble_row<T, 12, kTileWDev>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+    else e = assemble_row_wide<T>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+    me = fmax(me, e);
   }
+  block_max_256((double)me, blockMax);
 }
 
 // seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
@@ -625,7 +704,7 @@ struct fem_plan {
   // device assembly (FEM_PLAN_DEVICE_ASSEMBLY): connectivity SoA, positions, per-face records, entry tables
   bool can_assemble = false;
   fem_uint F = 0, Vg = 0;
-  DevBuf<fem_uint> tri0, tri1, tri2, topo;
+  DevBuf<fem_uint> tri0, tri1, tri2, topo, rowg;
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
   double *maxedge = nullptr, *blockmax = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
@@ -644,15 +723,34 @@ template <typename T> static int setPoints(fem_plan *p, const double *pts) {
 
 template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
   typedef typename Vec<T>::t4 T4;
-  hipLaunchKernelGGL(assemble_faces_kernel<T>, dim3((p->F + 255) / 256), dim3(256), 0, st, (const T4 *)p->pos, p->tri0.p,
-                     p->tri1.p, p->tri2.p, (T4 *)p->rec, p->F, p->blockmax);
-  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, (p->F + 255) / 256, p->maxedge);
-  if (p->ksteps > 0)
-    hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(p->ntiles), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
-                       p->tmeta.p, p->txinfo.p, (T4 *)p->tcoef, (fem_uint)kTileW);
-  else
-    hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(p->nblocks), dim3(256), 0, st, (const T4 *)p->rec, p->topo.p,
-                       p->slice_off.p, (T4 *)p->coef, p->nslices);
+  fem_uint nb;
+  if (p->ksteps > 0) {
+    nb = p->ntiles;
+    hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint4 *)p->topo.p,
+                       p->tmeta.p, p->tghost.p, p->txinfo.p, p->rowg.p, (T4 *)p->tcoef, (fem_uint)kTileW, p->blockmax);
+  } else {
+    nb = p->nblocks;
+    hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint4 *)p->topo.p,
+                       p->slice_off.p, p->rowg.p, (T4 *)p->coef, p->nslices, p->V, p->blockmax);
+  }
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, nb, p->maxedge);
+}
+
+// per-face records (fem_plan_face_records): not needed by the operator, computed on request
+template <typename T> static hipError_t launchFaceRecords(fem_plan *p) {
+  typedef typename Vec<T>::t4 T4;
+  if (!p->rec) {
+    hipError_t e = hipMalloc(&p->rec, 4 * sizeof(T4) * (size_t)(p->F ? p->F : 1));
+    if (e != hipSuccess) return e;
+  }
+  double *bm = nullptr;
+  hipError_t e = hipMalloc((void **)&bm, 8 * (size_t)((p->F + 255) / 256 + 1));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(assemble_faces_kernel<T>, dim3((p->F + 255) / 256), dim3(256), 0, 0, (const T4 *)p->pos, p->tri0.p,
+                     p->tri1.p, p->tri2.p, (T4 *)p->rec, p->F, bm);
+  e = hipDeviceSynchronize();
+  (void)hipFree(bm);
+  return e;
 }
 
 template <typename T> static int downloadAs(const void *dev, size_t count, double *out) {
@@ -835,7 +933,7 @@ void fem_plan_destroy(fem_plan *p) {
   if (!p) return;
   p->slice_off.release(); p->idx.release(); p->send_idx.release();
   p->tmeta.release(); p->tghost.release(); p->tidx2.release(); p->txinfo.release();
-  p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release();
+  p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release(); p->rowg.release();
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
   if (p->coef) (void)hipFree(p->coef);
@@ -920,9 +1018,10 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     const std::vector<fem_uint> &topo = ksteps > 0 ? TL.topo : L.topo;
     ok(p->tri0.alloc(p->F)) && ok(p->tri0.upload(t0.data())) && ok(p->tri1.alloc(p->F)) && ok(p->tri1.upload(t1.data())) &&
     ok(p->tri2.alloc(p->F)) && ok(p->tri2.upload(t2.data())) && ok(p->topo.alloc(topo.size())) && ok(p->topo.upload(topo.data())) &&
+    ok(p->rowg.alloc(op.rowg.size())) && ok(p->rowg.upload(op.rowg.data())) &&
     ok(hipMalloc(&p->pos, 4 * sb * p->Vg)) && ok(hipMalloc(&p->pos0, 4 * sb * p->Vg)) &&
-    ok(hipMalloc(&p->rec, 16 * sb * (p->F ? p->F : 1))) && ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8)) &&
-    ok(hipMalloc((void **)&p->blockmax, 8 * (size_t)((p->F + 255) / 256 + 1)));
+    ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8)) &&
+    ok(hipMalloc((void **)&p->blockmax, 8 * (size_t)(std::max<size_t>(ksteps > 0 ? TL.ntiles : (L.nslices + 3) / 4, 1))));
   }
   if (e == hipSuccess && shard)
     ok(p->send_idx.alloc(shard->send_idx.size())) && (shard->send_idx.empty() || ok(p->send_idx.upload(shard->send_idx.data())));
@@ -1097,6 +1196,7 @@ int fem_plan_max_edge(fem_plan *p, double *maxEdgeLen) {
 
 int fem_plan_face_records(fem_plan *p, double *rec16F) {
   if (!p || !p->can_assemble || !rec16F) return fail(FEM_ERR_INVALID, "fem_plan_face_records: bad argument");
+  HIP_TRY(p->precision == FEM_PREC_F32 ? launchFaceRecords<float>(p) : launchFaceRecords<double>(p));
   return p->precision == FEM_PREC_F32 ? downloadAs<float>(p->rec, 16 * (size_t)p->F, rec16F)
                                       : downloadAs<double>(p->rec, 16 * (size_t)p->F, rec16F);
 }

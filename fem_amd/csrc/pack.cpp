@@ -119,7 +119,8 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
   for (uint r = 0; r < V; r++) { const uint v = loc2glob ? loc2glob[r] : r; nnzMax += m.rowptr[v + 1] - m.rowptr[v]; }
   if (nnzMax > 0xffffffffull) return FEM_ERR_LIMIT;
   o.col.reserve(nnzMax);
-  o.f1.reserve(nnzMax); o.f2.reserve(nnzMax);
+  o.nb.reserve(4 * nnzMax);
+  o.rowg.resize(V);
   o.coef.reserve(4 * nnzMax);
 
   auto hatGrad = [&](int f, int corner, double *g) {   // corner 0 (a): gradVec12, 1 (b): gradVec13, 2 (c): -(both)
@@ -131,6 +132,7 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
 
   for (uint row = 0; row < V; row++) {
     const uint v = loc2glob ? loc2glob[row] : row;
+    o.rowg[row] = v;
     double theta = 0;
     for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
       const int h = m.row_he[e];
@@ -159,9 +161,12 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
         for (int d = 0; d < 3; d++) C[d] /= theta;
       }
       o.col.push_back(lc);
-      // faces on the two sides of edge (v, j) with v's corner in each (face << 2 | corner)
-      o.f1.push_back(h < H3 ? ((uint)(h / 3) << 2) | (uint)(h % 3) : 0xffffffffu);
-      o.f2.push_back(ho < H3 ? ((uint)(ho / 3) << 2) | (uint)((ho % 3 + 1) % 3) : 0xffffffffu);
+      // device assembly: the neighbour and the vertices opposite the edge (v, j) in the faces left
+      // of v->j and of j->v (mesh vertex ids; ~0 = no face on that side), flag 1 = real entry
+      o.nb.push_back(m.col[e]);
+      o.nb.push_back(h < H3 ? m.faces[SimpleTriMesh::prev_halfedge(h)] : 0xffffffffu);
+      o.nb.push_back(ho < H3 ? m.faces[SimpleTriMesh::prev_halfedge(ho)] : 0xffffffffu);
+      o.nb.push_back(1u);
       o.coef.push_back(s.wHej[h]);
       o.coef.push_back(C[0]); o.coef.push_back(C[1]); o.coef.push_back(C[2]);
     }
@@ -188,7 +193,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
   const size_t entries = o.slice_off[o.nslices];
   o.idx.resize(entries);
   o.coef.assign(4 * entries, 0.0);
-  o.topo.assign(2 * entries, 0xffffffffu);
+  o.topo.assign(4 * entries, 0u);
   for (uint sl = 0; sl < o.nslices; sl++) {
     const uint off = o.slice_off[sl], width = (o.slice_off[sl + 1] - off) / 64;
     for (uint lane = 0; lane < 64; lane++) {
@@ -200,7 +205,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
       for (uint e = op.rowptr[row]; e < op.rowptr[row + 1]; e++, k++) {
         const size_t pos = off + (size_t)k * 64 + lane;
         o.idx[pos] = op.col[e];
-        o.topo[2 * pos] = op.f1[e]; o.topo[2 * pos + 1] = op.f2[e];
+        for (int d = 0; d < 4; d++) o.topo[4 * pos + d] = op.nb[4 * (size_t)e + d];
         for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)e + d];
       }
     }
@@ -296,7 +301,7 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
     o.meta.insert(o.meta.end(), meta, meta + 16);
     o.ghost.insert(o.ghost.end(), local.begin() + m[0], local.end());
     o.coef.resize(4 * (rowOff + blockEntries), 0.0);
-    o.topo.resize(2 * (rowOff + blockEntries), 0xffffffffu);
+    o.topo.resize(4 * (rowOff + blockEntries), 0u);
     o.idx2.resize((rowOff + blockEntries) / 2, 0u);
     if (xcount) o.xinfo.resize(xOff + rowsPad + xcount, 0u);
     uint xnext = 0;
@@ -316,7 +321,7 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
             o.xinfo[xOff + rowsPad + xnext] = locId[op.col[q]];
             pos = rowOff + (size_t)W * rowsPad + xnext++;
           }
-          o.topo[2 * pos] = op.f1[q]; o.topo[2 * pos + 1] = op.f2[q];
+          for (int d = 0; d < 4; d++) o.topo[4 * pos + d] = op.nb[4 * (size_t)q + d];
           for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)q + d];
         }
         if (xnext > xfirst) o.xinfo[xOff + r] = xfirst | ((xnext - xfirst) << 16);
