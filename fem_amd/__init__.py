@@ -57,6 +57,8 @@ lib.fem_plan_operator_bytes.restype = C.c_uint64
 lib.fem_plan_operator_bytes.argtypes = [vp]
 lib.fem_free.argtypes = [vp]
 lib.fem_plan_pack_halo.argtypes = [vp, C.c_uint64, vp]
+lib.fem_plan_pack_halo_from.argtypes = [vp, C.c_int, C.c_uint64, vp]
+lib.fem_plan_launch_tiles.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, vp, vp]
 lib.fem_plan_coef_count.restype = C.c_uint64
 lib.fem_plan_coef_count.argtypes = [vp]
 for _name in ("fem_mesh_destroy", "fem_ref_layout_destroy", "fem_ref_device_destroy", "fem_plan_destroy",
@@ -435,8 +437,28 @@ class Plan:
         return dict(ksteps=k.value, ntiles=nt.value, max_local=ml.value, rows_loaded=rows.value,
                     threads=thr.value, rows_per_thread=rpt.value)
 
-    def pack_halo(self, dst_ptr, stream=None):
-        _check(lib.fem_plan_pack_halo(self.h, C.c_uint64(dst_ptr), vp(stream or 0)))
+    def pack_halo(self, dst_ptr, stream=None, which=0):
+        """which = 0: from the current state buffer, 1: from the next one (see launch_tiles)"""
+        _check(lib.fem_plan_pack_halo_from(self.h, which, dst_ptr, vp(stream or 0)))
+
+    def tile_classes(self):
+        """(interior, boundary, ghost) tile counts; the tiles are ordered in that sequence"""
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _check(lib.fem_plan_tile_classes(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def launch_tiles(self, first, count, nsteps, dt, model=None, stream=None):
+        """nsteps <= ksteps fused steps of tiles [first, first+count): current buffer -> next; no flip"""
+        mp = C.cast(C.byref(model), vp) if model is not None else None
+        _check(lib.fem_plan_launch_tiles(self.h, first, count, nsteps, dt, mp, vp(stream or 0)))
+
+    def flip(self):
+        _check(lib.fem_plan_flip(self.h))
+
+    def state_buffer(self, which=0):
+        p = C.c_uint64()
+        _check(lib.fem_plan_state_buffer(self.h, which, C.byref(p)))
+        return p.value
 
     def __del__(self):
         if getattr(self, "h", None) and lib is not None:

@@ -214,13 +214,13 @@ template <typename T, int TPB, int R, int W, int MINW, bool X>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
-    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint ntiles, uint maxLocal,
-    uint maxExtra, int nsteps, ModelT<T> m) {
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
+    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   extern __shared__ __align__(16) unsigned char tile_smem[];
   const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
-  const uint tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);
+  const uint tile = tile0 + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);   // tiles [tile0, tile0 + ntiles)
   const uint *mt = meta + 16 * (size_t)tile;
   const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], k = mt[4];
   const uint n0 = mt[5], mk = mt[5 + k];
@@ -697,6 +697,7 @@ struct fem_plan {
   // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
   int ksteps = 0, tcfg = 0;
   fem_uint ntiles = 0, maxLocal = 0, maxExtra = 0;
+  fem_uint nInterior = 0, nBoundary = 0, nGhost = 0;   // tile classes of a shard's plan, in this order
   uint64_t tile_rows = 0, tile_entries = 0;
   uint64_t tile_bytes = 0;
   DevBuf<fem_uint> tmeta, tghost, tidx2, txinfo;
@@ -762,7 +763,8 @@ template <typename T> static int downloadAs(const void *dev, size_t count, doubl
 }
 
 template <typename T, int C>
-static hipError_t launchTile(fem_plan *p, const void *src, void *dst, int nsteps, const ModelT<T> &m, hipStream_t stream) {
+static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const void *src, void *dst, int nsteps,
+                             const ModelT<T> &m, hipStream_t stream) {
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
@@ -773,8 +775,9 @@ static hipError_t launchTile(fem_plan *p, const void *src, void *dst, int nsteps
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(p->ntiles), dim3(TPB), lds, stream, (const T2 *)src, (T2 *)dst, p->tmeta.p,
-                     p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra,
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(kern, dim3(count), dim3(TPB), lds, stream, (const T2 *)src, (T2 *)dst, p->tmeta.p,
+                     p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->txinfo.p, first, count, p->maxLocal, p->maxExtra,
                      nsteps, m);
   return hipSuccess;
 }
@@ -955,6 +958,7 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh has no topology/stats or is too large");
   fem::SellLayout L;
   fem::TileLayout TL;
+  std::vector<unsigned char> tileClass;
   int tcfg = 0;
   if (ksteps > 0) {
     // tiles = this rank's partitions, then (shards only) the ghost rows in pieces
@@ -974,6 +978,33 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
                              precision == FEM_PREC_F32 ? kTileMaxLocal : kTileMaxLocal * 3 / 4, kTileMaxExtra, TL);
     if (rc == FEM_ERR_LIMIT) return fail(rc, "fem_plan_create_tiled: a partition cannot be cut into tiles that fit the fused kernel");
     if (rc != FEM_OK) return fail(rc, "fem_plan_create_tiled: cannot tile");
+    // Shards: order the tiles [interior | boundary | ghost] so that a launch can take a class
+    // range (DESIGN.md "Multi-GPU": exchange overlapped with the interior tiles).
+    //   ghost    = tiles of ghost rows (their last group before an exchange is never consumed);
+    //   boundary = owned tiles that stage a ghost row (need the exchange before they run) or hold
+    //              a row another rank needs (must be done before the exchange is packed);
+    //   interior = the rest.
+    tileClass.assign(TL.ntiles, 0);
+    if (shard) {
+      const fem::uint nOwn = own_e - own_b;
+      std::vector<unsigned char> isSend(op.V, 0);
+      for (fem::uint i : shard->send_idx) if (i < op.V) isSend[i] = 1;
+      for (fem::uint t = 0; t < TL.ntiles; t++) {
+        const fem::uint *mt = &TL.meta[16 * (size_t)t];
+        const fem::uint base = mt[0], goff = mt[1], k = mt[4], m0 = mt[5], mk = mt[5 + k];
+        if (base >= nOwn) { tileClass[t] = 2; continue; }
+        bool bnd = false;
+        for (fem::uint i = 0; i < mk - m0 && !bnd; i++) bnd = TL.ghost[goff + i] >= nOwn;
+        for (fem::uint i = 0; i < m0 && !bnd; i++) bnd = isSend[base + i] != 0;
+        tileClass[t] = bnd ? 1 : 0;
+      }
+      std::vector<fem::uint> order(TL.ntiles), meta2(TL.meta.size());
+      for (fem::uint t = 0; t < TL.ntiles; t++) order[t] = t;
+      std::stable_sort(order.begin(), order.end(), [&](fem::uint a, fem::uint b) { return tileClass[a] < tileClass[b]; });
+      for (fem::uint t = 0; t < TL.ntiles; t++)
+        std::copy(&TL.meta[16 * (size_t)order[t]], &TL.meta[16 * (size_t)order[t]] + 16, &meta2[16 * (size_t)t]);
+      TL.meta.swap(meta2);
+    }
   } else {
     rc = fem::packSellLayout(op, L);
     if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh too large");
@@ -995,6 +1026,7 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   };
   if (ksteps > 0) {
     p->ksteps = ksteps; p->ntiles = TL.ntiles; p->tcfg = tcfg; p->tile_rows = TL.rowSteps;
+    for (unsigned char c : tileClass) (c == 0 ? p->nInterior : (c == 1 ? p->nBoundary : p->nGhost))++;
     p->maxLocal = (TL.maxLocal + 1) & ~1u; p->maxExtra = TL.maxExtra; p->tile_entries = TL.coef.size() / 4;
     p->tile_bytes = (uint64_t)(TL.coef.size() / 4) * (4 * sb + 2) + (uint64_t)TL.ghost.size() * 4 + (uint64_t)TL.meta.size() * 4 +
                     (uint64_t)TL.xinfo.size() * 4;
@@ -1060,17 +1092,26 @@ int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int p
   return planCreate(ordered, &shard->s, precision, model, 0, 0, nullptr, 0, out);
 }
 
-int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream) {
-  if (!p) return fail(FEM_ERR_INVALID, "fem_plan_pack_halo: null");
+int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream) { return fem_plan_pack_halo_from(p, 0, dst_dev, stream); }
+
+int fem_plan_state_buffer(const fem_plan *p, int which, uint64_t *dev_ptr) {
+  if (!p || !dev_ptr || (which != 0 && which != 1)) return fail(FEM_ERR_INVALID, "fem_plan_state_buffer: bad argument");
+  *dev_ptr = (uint64_t)p->state[p->cur ^ which];
+  return FEM_OK;
+}
+
+int fem_plan_pack_halo_from(fem_plan *p, int which, uint64_t dst_dev, void *stream) {
+  if (!p || (which != 0 && which != 1)) return fail(FEM_ERR_INVALID, "fem_plan_pack_halo: bad argument");
+  const void *from = p->state[p->cur ^ which];
   const fem_uint n = (fem_uint)p->send_idx.n;
   if (n == 0) return FEM_OK;
   if (!dst_dev) return fail(FEM_ERR_INVALID, "fem_plan_pack_halo: null destination");
   if (p->precision == FEM_PREC_F32)
     hipLaunchKernelGGL(pack_halo_kernel<float2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const float2 *)p->state[p->cur], p->send_idx.p, (float2 *)dst_dev, n);
+                       (const float2 *)from, p->send_idx.p, (float2 *)dst_dev, n);
   else
     hipLaunchKernelGGL(pack_halo_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       (const double2 *)p->state[p->cur], p->send_idx.p, (double2 *)dst_dev, n);
+                       (const double2 *)from, p->send_idx.p, (double2 *)dst_dev, n);
   HIP_TRY(hipGetLastError());
   return FEM_OK;
 }
@@ -1104,33 +1145,71 @@ int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn) {
   return FEM_OK;
 }
 
-int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream) {
-  if (!p || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_plan_run: bad argument");
+static int launchTiles(fem_plan *p, fem_uint first, fem_uint count, int nsteps, double dt, const fem_model *model,
+                       void *stream) {
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   ModelT<float> mf = {(float)(model->nMax - p->base_n), (float)model->D, (float)model->r, (float)model->alpha,
                       (float)model->S, (float)dt, (float)p->base_n, (float)(1.0 / (1.0 + p->base_n))};
   ModelT<double> md = {model->nMax - p->base_n, model->D, model->r, model->alpha, model->S, dt, p->base_n,
                        1.0 / (1.0 + p->base_n)};
+  void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
+  hipError_t e = hipSuccess;
+#define FEM_TILE_CASE(C)                                                                                       \
+  case C:                                                                                                      \
+    e = p->precision == FEM_PREC_F32 ? launchTile<float, C>(p, first, count, src, dst, nsteps, mf, (hipStream_t)stream) \
+                                     : launchTile<double, C>(p, first, count, src, dst, nsteps, md, (hipStream_t)stream); \
+    break;
+  switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) FEM_TILE_CASE(5) }
+#undef FEM_TILE_CASE
+  if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "tile_step_kernel launch", e);
+  return FEM_OK;
+}
+
+int fem_plan_launch_tiles(fem_plan *p, fem_uint first, fem_uint count, int nsteps, double dt, const fem_model *model,
+                          void *stream) {
+  if (!p || p->ksteps <= 0) return fail(FEM_ERR_INVALID, "fem_plan_launch_tiles: not a tiled plan");
+  if (nsteps < 1 || nsteps > p->ksteps || first > p->ntiles || count > p->ntiles - first)
+    return fail(FEM_ERR_INVALID, "fem_plan_launch_tiles: tile range or step count out of range");
+  const int rc = launchTiles(p, first, count, nsteps, dt, model, stream);
+  if (rc != FEM_OK) return rc;
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+int fem_plan_flip(fem_plan *p) {
+  if (!p) return fail(FEM_ERR_INVALID, "fem_plan_flip: null");
+  p->cur ^= 1;
+  return FEM_OK;
+}
+
+int fem_plan_tile_classes(const fem_plan *p, fem_uint *n_interior, fem_uint *n_boundary, fem_uint *n_ghost) {
+  if (!p || p->ksteps <= 0) return fail(FEM_ERR_INVALID, "fem_plan_tile_classes: not a tiled plan");
+  if (n_interior) *n_interior = p->nInterior;
+  if (n_boundary) *n_boundary = p->nBoundary;
+  if (n_ghost) *n_ghost = p->nGhost;
+  return FEM_OK;
+}
+
+int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream) {
+  if (!p || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_plan_run: bad argument");
   if (p->ksteps > 0) {                       // fused tiles: up to ksteps time steps per launch
     for (int done = 0; done < nsteps;) {
       const int c = std::min(p->ksteps, nsteps - done);
-      void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
-      hipError_t e = hipSuccess;
-#define FEM_TILE_CASE(C)                                                                         \
-  case C:                                                                                        \
-    e = p->precision == FEM_PREC_F32 ? launchTile<float, C>(p, src, dst, c, mf, (hipStream_t)stream) \
-                                     : launchTile<double, C>(p, src, dst, c, md, (hipStream_t)stream); \
-    break;
-      switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) FEM_TILE_CASE(5) }
-#undef FEM_TILE_CASE
-      if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "tile_step_kernel launch", e);
+      const int rc = launchTiles(p, 0, p->ntiles, c, dt, model, stream);
+      if (rc != FEM_OK) return rc;
       p->cur ^= 1;
       done += c;
     }
     HIP_TRY(hipGetLastError());
     return FEM_OK;
   }
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  ModelT<float> mf = {(float)(model->nMax - p->base_n), (float)model->D, (float)model->r, (float)model->alpha,
+                      (float)model->S, (float)dt, (float)p->base_n, (float)(1.0 / (1.0 + p->base_n))};
+  ModelT<double> md = {model->nMax - p->base_n, model->D, model->r, model->alpha, model->S, dt, p->base_n,
+                       1.0 / (1.0 + p->base_n)};
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
     if (p->precision == FEM_PREC_F32)

@@ -79,13 +79,23 @@ class HipShardStepper:
     def step(self, nsteps, dt, model, stream):
         self.plan.run(nsteps, dt, model, stream.cuda_stream if stream is not None else None)
 
-    def pack(self, stream):
-        self.plan.pack_halo(self.sendbuf.data_ptr(), stream.cuda_stream if stream is not None else None)
+    def pack(self, stream, which=0):
+        self.plan.pack_halo(self.sendbuf.data_ptr(), stream.cuda_stream if stream is not None else None, which)
         return self.sendbuf[:self.shard.n_send]
 
-    def ghost_view(self):
-        """tensor aliasing the ghost segment of the plan's CURRENT state buffer"""
-        ptr = self.plan.state_ptr()[0]
+    def tile_classes(self):
+        """(interior, boundary, ghost) tile counts of a fused plan, None for a sliced-ELL plan"""
+        return self.plan.tile_classes() if self.plan.tile_info()["ksteps"] > 0 else None
+
+    def launch(self, first, count, nsteps, dt, model, stream):
+        self.plan.launch_tiles(first, count, nsteps, dt, model, stream.cuda_stream if stream is not None else None)
+
+    def flip(self):
+        self.plan.flip()
+
+    def ghost_view(self, which=0):
+        """tensor aliasing the ghost segment of the plan's current (which = 0) or next (1) state buffer"""
+        ptr = self.plan.state_buffer(which)
         if ptr not in self._views:
             full = self.torch.as_tensor(_DevView(ptr, (self.shard.n_local, 2), self.typestr), device="cuda")
             self._views[ptr] = full[self.shard.n_own:]
@@ -96,22 +106,25 @@ class HipShardStepper:
         return n[:self.shard.n_own], c[:self.shard.n_own]
 
 
-def exchange_halo(stepper, shard, stream=None, group=None):
+def exchange_halo(stepper, shard, stream=None, group=None, which=0, async_op=False):
     """one all-to-all-v of boundary state: each rank's send vertices -> the ghost segments of its
-    neighbours' current state buffers.  RCCL (backend nccl) moves device memory directly; with
-    gloo (CPU tests, or several ranks sharing one GPU) the buffers are staged through the host."""
+    neighbours' state buffers (which = 0 current, 1 next).  RCCL (backend nccl) moves device
+    memory directly and, with async_op, returns a work handle: kernels launched afterwards on the
+    compute stream run beside the exchange until handle.wait().  With gloo (CPU tests, or several
+    ranks sharing one GPU) the buffers are staged through the host, synchronously."""
     import torch
     import torch.distributed as dist
-    send = stepper.pack(stream)
-    recv = stepper.ghost_view()
+    send = stepper.pack(stream, which) if which else stepper.pack(stream)
+    recv = stepper.ghost_view(which) if which else stepper.ghost_view()
     in_splits, out_splits = [int(x) for x in shard.send_counts], [int(x) for x in shard.recv_counts]
     if dist.get_backend(group) == "gloo" and send.is_cuda:
         torch.cuda.synchronize()
         send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(recv_h, send_h, out_splits, in_splits, group=group)
         recv.copy_(recv_h)
-    else:
-        dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group)
+        torch.cuda.synchronize()
+        return None
+    return dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group, async_op=async_op)
 
 
 class ShardedRun:
@@ -140,6 +153,9 @@ class ShardedRun:
         self.plan = getattr(self.stepper, "plan", None)
         self.V = om.V
         self.budget = self.krings                                  # ghosts are fresh: k steps allowed
+        self.pending, self.pending_exchange = None, False          # exchange in flight (overlapped schedule)
+        tc = getattr(self.stepper, "tile_classes", None)
+        self.classes = tc() if (tc is not None and os.environ.get("FEM_OVERLAP", "1") != "0") else None
         # one exchange up front (re-sends the ghosts' own initial values): brings up the RCCL
         # communicator and its buffers outside any timed region
         import torch.distributed as dist
@@ -151,6 +167,8 @@ class ShardedRun:
         self.layout_bytes_per_launch = (plan.operator_bytes() + 4 * sb * self.shard.n_local) if plan else None
 
     def run(self, nsteps, stream=None):
+        if self.classes is not None:
+            return self._run_overlapped(nsteps, stream)
         done = 0
         while done < nsteps:
             if self.budget == 0:
@@ -161,7 +179,44 @@ class ShardedRun:
             self.budget -= chunk
             done += chunk
 
+    def _run_overlapped(self, nsteps, stream):
+        """fused plans: the tiles come as [interior | boundary | ghost].  The group of steps that
+        uses up the ghost budget runs the boundary tiles first, packs and starts the exchange, and
+        lets the interior tiles run beside it; the ghost tiles are skipped there (the exchange
+        overwrites them).  The first group after an exchange runs the interior tiles (they read
+        no ghost row) before it waits for the exchange."""
+        nI, nB, nG = self.classes
+        st, dt, model = self.stepper, self.dt, self.model
+        done = 0
+        while done < nsteps:
+            s = min(self.ksteps, self.budget, nsteps - done)
+            first, last = self.pending_exchange, self.budget == s
+            if first:
+                st.launch(0, nI, s, dt, model, stream)
+                self._wait_exchange()
+            if last:
+                st.launch(nI, nB, s, dt, model, stream)
+                self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=True)
+                self.pending_exchange = True
+                if not first:
+                    st.launch(0, nI, s, dt, model, stream)
+                self.budget = self.krings
+            else:
+                if first:
+                    st.launch(nI, nB + nG, s, dt, model, stream)
+                else:
+                    st.launch(0, nI + nB + nG, s, dt, model, stream)
+                self.budget -= s
+            st.flip()
+            done += s
+
+    def _wait_exchange(self):
+        if self.pending is not None:
+            self.pending.wait()
+        self.pending, self.pending_exchange = None, False
+
     def get_owned(self):
+        self._wait_exchange()
         return self.stepper.get_owned()
 
     def measured_traffic(self):

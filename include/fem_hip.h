@@ -306,6 +306,22 @@ int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int p
  * pairs of the plan's scalar type, device memory), async on `stream`. */
 int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream);
 
+/* Pieces of fem_plan_run for a caller that overlaps the halo exchange with the time steps (no
+ * counterpart in the single-GPU reference; DESIGN.md "Multi-GPU").  The tiles of a shard's fused
+ * plan are ordered [interior | boundary | ghost]: ghost = tiles of ghost rows; boundary = owned
+ * tiles that read a ghost row or hold a row another rank needs; interior = the rest (a plan of
+ * a whole mesh has interior tiles only).
+ *   fem_plan_launch_tiles: 1 <= nsteps <= ksteps fused steps of tiles [first, first+count) from
+ *     the current state buffer into the other ("next") one; does not flip;
+ *   fem_plan_flip: next becomes current (call once every tile that matters has been launched);
+ *   fem_plan_state_buffer / fem_plan_pack_halo_from: which = 0 current, 1 next. */
+int fem_plan_tile_classes(const fem_plan *p, fem_uint *n_interior, fem_uint *n_boundary, fem_uint *n_ghost);
+int fem_plan_launch_tiles(fem_plan *p, fem_uint first, fem_uint count, int nsteps, double dt,
+                          const fem_model *model, void *stream);
+int fem_plan_flip(fem_plan *p);
+int fem_plan_state_buffer(const fem_plan *p, int which, uint64_t *dev_ptr);
+int fem_plan_pack_halo_from(fem_plan *p, int which, uint64_t dst_dev, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,7 @@ run = ShardedRun(fa.Mesh(pts, tri), a.nparts, rank, world, a.precision, seed=3, 
 run.run(a.steps // 2, stream)
 run.run(a.steps - a.steps // 2, stream)
 n, c = run.get_owned()
-np.savez(a.out + ".%d.npz" % rank, n=n, c=c, own_begin=run.shard.own_begin, own_end=run.shard.own_end, dt=run.dt)
+np.savez(a.out + ".%d.npz" % rank, n=n, c=c, own_begin=run.shard.own_begin, own_end=run.shard.own_end, dt=run.dt,
+         classes=np.array(run.classes if run.classes is not None else (-1, -1, -1)))
 dist.barrier()
 dist.destroy_process_group()

@@ -27,10 +27,14 @@ def reference_run(nu, nparts, steps, seed=3):
     return part, st.step(n0, c0, dt, steps, fa.default_model().as_array())
 
 
+_launches = [0]
+
+
 def launch(world, tmp_path, **kw):
     out = str(tmp_path / "shard")
+    _launches[0] += 1
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 2000),
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + (os.getpid() * 16 + _launches[0]) % 2000),
            os.path.join(ROOT, "tests", "dist_worker.py"), "--out", out]
     for k, v in kw.items():
         cmd += ["--" + k, str(v)]
@@ -128,11 +132,62 @@ def test_gpu_shards_loopback(world, krings, precision, ksteps):
 
 
 @pytest.mark.gpu
-def test_gpu_two_ranks_gloo(tmp_path):
-    """ShardedRun with the HIP stepper as 2 processes sharing the card (exchange staged via gloo)"""
-    nu, nparts, steps = 16, 12, 11
+@pytest.mark.parametrize("nu,nparts,world,krings,fuse,precision,overlap", [
+    (32, 96, 2, 4, 2, "f64", "1"),    # two groups per exchange: [all] then [boundary | exchange || interior]
+    (32, 96, 3, 3, 3, "f64", "1"),    # one group per exchange: interior, wait, boundary, exchange
+    (16, 12, 2, 6, 4, "f64", "1"),    # groups of 4 + 2 steps; every tile is a boundary tile
+    (32, 96, 2, 4, 2, "f64", "0"),    # FEM_OVERLAP=0: plain schedule
+    (16, 12, 2, 2, 0, "f64", "1"),    # sliced-ELL plans: plain schedule
+])
+def test_gpu_ranks_gloo(tmp_path, nu, nparts, world, krings, fuse, precision, overlap, monkeypatch):
+    """ShardedRun with the HIP stepper as several processes sharing the card (exchange staged via
+    gloo): the overlapped schedule over the [interior | boundary | ghost] tile classes"""
+    steps = 11
     part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
-    res = launch(2, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=4, steps=steps, precision="f64", fuse=2)
+    monkeypatch.setenv("FEM_OVERLAP", overlap)
+    res = launch(world, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=krings, steps=steps,
+                 precision=precision, fuse=fuse)
     for r in res:
         b, e = int(r["own_begin"]), int(r["own_end"])
         assert rel_l2(r["n"], n_ref[b:e]) <= 1e-11 and rel_l2(r["c"], c_ref[b:e]) <= 1e-11
+        if overlap == "1" and fuse > 0:
+            nI, nB, nG = r["classes"]
+            assert nB > 0 and nG > 0 and (nI > 0 or nu < 32)      # the big case exercises all three classes
+        else:
+            assert tuple(r["classes"]) == (-1, -1, -1)
+
+
+@pytest.mark.gpu
+def test_gpu_tile_classes():
+    """the class ranges cover the tiles; a whole-mesh plan is all interior; launching the classes
+    one by one equals one launch of everything"""
+    nu, nparts = 24, 40
+    part, _ = reference_run(nu, nparts, 0)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
+    n0, c0 = fa.initial_condition(om.V, 3)
+    whole = fa.Plan(om, fa.PREC_F64, part=part, ksteps=3)
+    assert whole.tile_classes() == (whole.tile_info()["ntiles"], 0, 0)
+    shard = fa.Shard(part, 1, 3, 3)
+    outs = []
+    for split in (False, True):
+        plan = fa.Plan(om, fa.PREC_F64, shard=shard, part=part, ksteps=3)
+        nI, nB, nG = plan.tile_classes()
+        assert nI + nB + nG == plan.tile_info()["ntiles"] and nB > 0 and nG > 0
+        plan.set_state(n0[shard.loc2glob], c0[shard.loc2glob])
+        if split:
+            plan.launch_tiles(nI + nB, nG, 3, dt)
+            plan.launch_tiles(0, nI, 3, dt)
+            plan.launch_tiles(nI, nB, 3, dt)
+            plan.flip()
+        else:
+            plan.run(3, dt)
+        outs.append(plan.get_state())
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    with pytest.raises(fa.FemError):
+        plan.launch_tiles(0, nI + nB + nG + 1, 3, dt)
+    with pytest.raises(fa.FemError):
+        plan.launch_tiles(0, 1, 4, dt)                      # more steps than the plan fuses
+    with pytest.raises(fa.FemError):
+        fa.Plan(om, fa.PREC_F64).tile_classes()             # sliced-ELL plan
