@@ -117,6 +117,16 @@ def main():
     else:
         from fem_amd import dist as fdist
         runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse, dt_rule=dt_rule)
+    mesh_report = None
+    if scanned and rank == 0:           # config 4: valence histogram and partition imbalance
+        import numpy as np
+        val = np.bincount(tri.ravel().astype(np.int64), minlength=V_total)
+        sizes = np.diff(runner.part.node_parts.astype(np.int64))
+        fsizes = np.diff(runner.part.element_parts.astype(np.int64))[:-1]
+        mesh_report = {"valence_histogram": np.bincount(val).tolist(),
+                       "partition_vertices_min_mean_max": [int(sizes.min()), float(sizes.mean()), int(sizes.max())],
+                       "partition_interior_faces_min_mean_max": [int(fsizes.min()), float(fsizes.mean()), int(fsizes.max())],
+                       "cut_faces_fraction": float((runner.part.element_parts[-1] - runner.part.element_parts[-2]) / len(tri))}
     del pts, tri, mesh
     t_host = time.perf_counter() - t_host
 
@@ -161,7 +171,7 @@ def main():
                                       if scanned else "class-I geodesic icosphere", wl["nu"], V_total, 2 * V_total - 4, nparts),
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
-                       "halo_rings": getattr(runner, "krings", None),
+                       "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report,
                        "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange" % world},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   // rows wider than W (irregular meshes): entries W, W+1, ... of all rows of the tile, in LDS
   T4 *xs_coef = reinterpret_cast<T4 *>(nxt + maxLocal);          // maxLocal is even: 16-B aligned
   uint *xs_off = reinterpret_cast<uint *>(xs_coef + maxExtra);
+  uint *xs_info = xs_off + maxExtra;                             // [T*R] rows of the register tile
   const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // X = false: plan without wide rows
   const uint t = threadIdx.x;
 
@@ -248,12 +249,8 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
 #pragma unroll
     for (int w = 0; w < W / 2; w++) ix[q][w] = tidx[w * rpad + r] * (uint)sizeof(T2);   // ids < 4096: both halves scale
   }
-  uint xi[R];                                            // first extra | count << 16 of each row
-#pragma unroll
-  for (int q = 0; q < R; q++) xi[q] = 0;
   if (X && xcnt) {                                       // tile-uniform
-#pragma unroll
-    for (int q = 0; q < R; q++) xi[q] = xinfo[xoff + min(t + TPB * q, rpad - 1)];
+    for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
     for (uint i = t; i < xcnt; i += TPB) {
       xs_coef[i] = tcoef[W * rpad + i];
       xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
@@ -302,14 +299,16 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
           gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
           gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
         }
-        if (X)
-        for (uint e = xi[q] & 0xffffu, ee = e + (xi[q] >> 16); e < ee; e++) {
-          const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
-          const T4 c = xs_coef[e];
-          const T dn = f.x - self.x, dc = f.y - self.y;
-          lapn += c.x * dn; lapc += c.x * dc;
-          gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
-          gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+        if (X && xcnt) {                                 // entries W, W+1, ... of a wide row
+          const uint xi = xs_info[r];
+          for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {
+            const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
+            const T4 c = xs_coef[e];
+            const T dn = f.x - self.x, dc = f.y - self.y;
+            lapn += c.x * dn; lapc += c.x * dc;
+            gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+            gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+          }
         }
         nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
       }
@@ -769,8 +768,10 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   typedef typename Vec<T>::t4 T4;
   constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
   constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : (TPB == 1024 ? 4 : (TPB == 512 ? 2 : 1));
-  auto kern = p->maxExtra ? tile_step_kernel<T, TPB, R, kTileW, MINW, true> : tile_step_kernel<T, TPB, R, kTileW, MINW, false>;
-  const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4);
+  static const bool forceX = getenv("FEM_TILE_FORCE_X") != nullptr;      // tuning probe: cost of the wide-row variant
+  auto kern = (p->maxExtra || forceX) ? tile_step_kernel<T, TPB, R, kTileW, MINW, true> : tile_step_kernel<T, TPB, R, kTileW, MINW, false>;
+  const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
+                     (p->maxExtra ? (size_t)TPB * R * 4 : 0);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
