@@ -2,11 +2,19 @@
 // Stands in for what the reference gets from OpenMesh (src/common.h:41-52,
 // src/main.cpp:156-167); conventions in fem_host.hpp / DESIGN.md.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <string>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "fem_host.hpp"
 
@@ -99,87 +107,315 @@ static bool readWholeFile(const std::string &path, std::vector<char> &buf) {
   return got == (size_t)n;
 }
 
+// Decimal -> double without strtod for the common case: up to 19 significant digits and a
+// decimal exponent within +-22 convert exactly with one multiply or divide by an exact power
+// of ten when the digits fit 2^53 (Clinger's fast path); anything else goes to strtod.
+static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11,
+                                  1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+static inline bool parseDouble(const char *&p, double &v, bool *sawPoint = nullptr) {
+  const char *s = p;
+  bool neg = false;
+  if (*s == '-' || *s == '+') { neg = *s == '-'; s++; }
+  uint64_t mant = 0;
+  int digits = 0, exp10 = 0;
+  const char *d0 = s;
+  while (*s >= '0' && *s <= '9') { if (digits < 19) { mant = mant * 10 + (uint64_t)(*s - '0'); digits += (mant != 0); } else exp10++; s++; }
+  bool any = s != d0;
+  if (*s == '.') {
+    if (sawPoint) *sawPoint = true;
+    s++;
+    const char *f0 = s;
+    while (*s >= '0' && *s <= '9') { if (digits < 19) { mant = mant * 10 + (uint64_t)(*s - '0'); digits += (mant != 0); exp10--; } s++; }
+    any = any || s != f0;
+  }
+  if (!any) {                                       // inf / nan spellings
+    char *e;
+    v = strtod(p, &e);
+    if (e == p) return false;
+    p = e;
+    return true;
+  }
+  if (*s == 'e' || *s == 'E') {
+    const char *e = s + 1;
+    bool eneg = false;
+    if (*e == '-' || *e == '+') { eneg = *e == '-'; e++; }
+    if (*e >= '0' && *e <= '9') {
+      int ex = 0;
+      while (*e >= '0' && *e <= '9') { if (ex < 10000) ex = ex * 10 + (*e - '0'); e++; }
+      exp10 += eneg ? -ex : ex;
+      s = e;
+      if (sawPoint) *sawPoint = true;
+    }
+  }
+  if (mant <= (1ull << 53) && exp10 >= -22 && exp10 <= 22) {
+    double x = (double)mant;
+    x = exp10 < 0 ? x / kPow10[-exp10] : x * kPow10[exp10];
+    v = neg ? -x : x;
+  } else {
+    char *e;
+    v = strtod(p, &e);                              // rare: long mantissas, huge exponents, inf/nan
+    if (e == p) return false;
+    s = e;
+  }
+  p = s;
+  return true;
+}
+
+// Whole file as a NUL-terminated byte range: mapped (no copy; the zero fill of the last page is
+// the terminator) unless the size is a multiple of the page size, then read into memory.
+struct FileBytes {
+  const char *data = nullptr;
+  size_t size = 0;
+  void *map = nullptr;
+  size_t mapLen = 0;
+  std::vector<char> buf;
+  bool open(const std::string &path) {
+    int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); return readWholeFile(path, buf) && adopt(); }
+    size = (size_t)st.st_size;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if (size == 0 || size % page == 0) { ::close(fd); return readWholeFile(path, buf) && adopt(); }
+    void *q = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (q == MAP_FAILED) return readWholeFile(path, buf) && adopt();
+    map = q; mapLen = size; data = (const char *)q;
+    return true;
+  }
+  bool adopt() { data = buf.data(); size = buf.size() - 1; return true; }
+  ~FileBytes() { if (map) munmap(map, mapLen); }
+};
+
 struct Cursor {
-  char *p;
+  const char *p, *end;
   void skip() {                                   // whitespace and '#' comments
     for (;;) {
       while (*p == ' ' || *p == '\t' || *p == '\r' || *p == '\n') p++;
       if (*p == '#') { while (*p && *p != '\n') p++; } else break;
     }
   }
+  void skipBlanks() { while (*p == ' ' || *p == '\t' || *p == '\r') p++; }
   bool eol() {                                    // only blanks left on this line?
-    char *q = p;
+    const char *q = p;
     while (*q == ' ' || *q == '\t' || *q == '\r') q++;
     return *q == '\n' || *q == 0 || *q == '#';
   }
-  bool num(double &v) { skip(); char *e; v = strtod(p, &e); if (e == p) return false; p = e; return true; }
-  bool integer(long &v) { skip(); char *e; v = strtol(p, &e, 10); if (e == p) return false; p = e; return true; }
+  bool num(double &v, bool *sawPoint = nullptr) { skip(); return parseDouble(p, v, sawPoint); }
+  bool integer(long &v) {
+    skip();
+    const char *s = p;
+    bool neg = false;
+    if (*s == '-' || *s == '+') { neg = *s == '-'; s++; }
+    if (*s < '0' || *s > '9') return false;
+    long x = 0;
+    while (*s >= '0' && *s <= '9') { x = x * 10 + (*s - '0'); s++; }
+    v = neg ? -x : x;
+    p = s;
+    return true;
+  }
 };
+
+static int hostThreads() {
+  const char *e = getenv("FEM_HOST_THREADS");
+  int n = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  return std::max(1, std::min(n, 64));
+}
+
+// One vertex record ("x y z [r g b [a]]") or one face record ("n i0 .. in-1 [colour]"); the
+// cursor stands at the record's first character and is left on the next record.
+static bool parseVertex(Cursor &c, bool hasColor, double *xyz, unsigned char *rgb) {
+  for (int k = 0; k < 3; k++)
+    if (!c.num(xyz[k])) return false;
+  if (hasColor) {
+    double col[4] = {0, 0, 0, 0};
+    int nc = 0;
+    bool isFloat = false;
+    while (nc < 4 && !c.eol()) {
+      if (!c.num(col[nc], &isFloat)) return false;
+      nc++;
+    }
+    if (nc < 3) return false;
+    for (int k = 0; k < 3; k++) {
+      double v = isFloat ? col[k] * 255.0 : col[k];
+      rgb[k] = (unsigned char)std::min(255.0, std::max(0.0, std::floor(v + 0.5)));
+    }
+  }
+  return true;
+}
+
+static bool parseFace(Cursor &c, long nv, std::vector<long> &poly, std::vector<uint> &tris) {
+  long n;
+  if (!c.integer(n) || n < 3) return false;
+  poly.resize((size_t)n);
+  for (long k = 0; k < n; k++)
+    if (!c.integer(poly[k]) || poly[k] < 0 || poly[k] >= nv) return false;
+  for (long k = 1; k + 1 < n; k++) { tris.push_back((uint)poly[0]); tris.push_back((uint)poly[k]); tris.push_back((uint)poly[k + 1]); }
+  while (*c.p && *c.p != '\n') c.p++;             // ignore trailing face colour
+  return true;
+}
 
 // OFF / COFF (optionally with per-vertex "r g b [a]"), polygons fan-triangulated
 // like a TriMesh import does.  Replaces OpenMesh::IO::read_mesh, main.cpp:156-167.
+// Built for 8-16M-vertex files: one read of the file, hand-rolled number parsing, and -- when
+// the body has one record per line, as every writer produces -- the lines split over host threads
+// (chunks cut at line ends; a counting pass gives every chunk its first record number, so vertex
+// i lands in slot i and the faces keep file order).  Files with records spanning lines or sharing
+// a line fall back to the sequential token parser.
 int readOFF(const std::string &path, SimpleTriMesh &m) {
-  std::vector<char> buf;
-  if (!readWholeFile(path, buf)) return FEM_ERR_IO;
-  Cursor c{buf.data()};
+  const bool timing = getenv("FEM_TIMING") != nullptr;
+  auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double t0 = now();
+  auto lap = [&](const char *what) { if (timing) { double t = now(); fprintf(stderr, "readOFF %s %.3f s\n", what, t - t0); t0 = t; } };
+  FileBytes file;
+  if (!file.open(path)) return FEM_ERR_IO;
+  lap("file");
+  Cursor c{file.data, file.data + file.size};
   c.skip();
-  char *w = c.p;
+  const char *w = c.p;
   while (*c.p && !isspace((unsigned char)*c.p)) c.p++;
   std::string magic(w, c.p);
   bool hasColor = magic.find('C') != std::string::npos;
   if (magic.size() < 3 || magic.compare(magic.size() - 3, 3, "OFF") != 0) return FEM_ERR_IO;
   long nv, nf, ne;
   if (!c.integer(nv) || !c.integer(nf) || !c.integer(ne) || nv < 0 || nf < 0) return FEM_ERR_IO;
+  if (nv > 0xfffffff0l || nf > 0xfffffff0l) return FEM_ERR_LIMIT;
   m.clean();
   m.points.resize(3 * (size_t)nv);
   if (hasColor) m.colors.resize(3 * (size_t)nv);
-  for (long i = 0; i < nv; i++) {
-    for (int k = 0; k < 3; k++)
-      if (!c.num(m.points[3 * i + k])) return FEM_ERR_IO;
-    if (hasColor) {
-      double col[4] = {0, 0, 0, 0};
-      int nc = 0;
-      bool isFloat = false;
-      while (nc < 4 && !c.eol()) {
-        char *s = c.p;
-        if (!c.num(col[nc])) return FEM_ERR_IO;
-        for (char *q = s; q < c.p; q++) if (*q == '.') isFloat = true;
-        nc++;
+  c.skip();
+  const char *body = c.p;
+  lap("header+alloc");
+
+  // ---- parallel path: records = non-blank, non-comment lines
+  const int T = (nv + nf >= 200000) ? hostThreads() : 1;
+  if (T > 1) {
+    std::vector<const char *> cut(T + 1);
+    cut[0] = body; cut[T] = c.end;
+    for (int t = 1; t < T; t++) {
+      const char *q = body + (size_t)(c.end - body) * t / T;
+      while (q < c.end && *q != '\n') q++;
+      cut[t] = q < c.end ? q + 1 : c.end;
+    }
+    auto isRecord = [](const char *q) {             // first non-blank char of the line starting at q
+      while (*q == ' ' || *q == '\t' || *q == '\r') q++;
+      return *q != '\n' && *q != 0 && *q != '#';
+    };
+    std::vector<long> count(T + 1, 0);
+    {
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+          long n = 0;
+          for (const char *q = cut[t]; q < cut[t + 1];) {
+            n += isRecord(q);
+            const char *nl = (const char *)memchr(q, '\n', (size_t)(cut[t + 1] - q));
+            q = nl ? nl + 1 : cut[t + 1];
+          }
+          count[t + 1] = n;
+        });
+      for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < T; t++) count[t + 1] += count[t];
+    lap("count lines");
+    if (count[T] == nv + nf) {                      // exactly one record per line
+      std::vector<std::vector<uint>> tris(T);
+      std::vector<int> ok(T, 1);
+      std::vector<std::thread> th;
+      for (int t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+          long rec = count[t];
+          std::vector<long> poly;
+          const long myFaces = count[t + 1] - std::max(count[t], nv);
+          if (myFaces > 0) tris[t].reserve(3 * (size_t)myFaces + 64);
+          for (const char *q = cut[t]; q < cut[t + 1];) {
+            const char *nl = (const char *)memchr(q, '\n', (size_t)(cut[t + 1] - q));
+            const char *next = nl ? nl + 1 : cut[t + 1];
+            if (isRecord(q)) {
+              Cursor lc{q, next};
+              bool good;
+              if (rec < nv) good = parseVertex(lc, hasColor, &m.points[3 * (size_t)rec], hasColor ? &m.colors[3 * (size_t)rec] : nullptr);
+              else good = parseFace(lc, nv, poly, tris[t]);
+              if (good) { lc.skipBlanks(); good = lc.p <= next && (rec >= nv || *lc.p == '\n' || *lc.p == 0 || *lc.p == '#'); }
+              if (!good) { ok[t] = 0; return; }
+              rec++;
+            }
+            q = next;
+          }
+        });
+      for (auto &x : th) x.join();
+      lap("parse");
+      bool allOk = true;
+      for (int t = 0; t < T; t++) allOk = allOk && ok[t];
+      if (allOk) {
+        size_t total = 0;
+        for (auto &v : tris) total += v.size();
+        m.faces.resize(total);
+        std::vector<size_t> off(T + 1, 0);
+        for (int t = 0; t < T; t++) off[t + 1] = off[t] + tris[t].size();
+        std::vector<std::thread> cp;
+        for (int t = 0; t < T; t++)
+          cp.emplace_back([&, t]() { std::copy(tris[t].begin(), tris[t].end(), m.faces.begin() + off[t]); });
+        for (auto &x : cp) x.join();
+        lap("concat");
+        return FEM_OK;
       }
-      if (nc < 3) return FEM_ERR_IO;
-      for (int k = 0; k < 3; k++) {
-        double v = isFloat ? col[k] * 255.0 : col[k];
-        m.colors[3 * i + k] = (unsigned char)std::min(255.0, std::max(0.0, std::floor(v + 0.5)));
-      }
+      // a record ran over its line (or is malformed): let the sequential parser decide
     }
   }
+
+  // ---- sequential token parser (records may span or share lines)
+  c.p = body;
+  for (long i = 0; i < nv; i++)
+    if (!parseVertex(c, hasColor, &m.points[3 * (size_t)i], hasColor ? &m.colors[3 * (size_t)i] : nullptr)) return FEM_ERR_IO;
   m.faces.reserve(3 * (size_t)nf);
   std::vector<long> poly;
-  for (long i = 0; i < nf; i++) {
-    long n;
-    if (!c.integer(n) || n < 3) return FEM_ERR_IO;
-    poly.resize((size_t)n);
-    for (long k = 0; k < n; k++)
-      if (!c.integer(poly[k]) || poly[k] < 0 || poly[k] >= nv) return FEM_ERR_IO;
-    for (long k = 1; k + 1 < n; k++) m.add_face((uint)poly[0], (uint)poly[k], (uint)poly[k + 1]);
-    while (*c.p && *c.p != '\n') c.p++;          // ignore trailing face colour
-  }
+  for (long i = 0; i < nf; i++)
+    if (!parseFace(c, nv, poly, m.faces)) return FEM_ERR_IO;
+  m.H = 0;
   return FEM_OK;
 }
 
+// COFF / OFF writer (the shape of ResultantPattern.off).  Records are formatted by host threads
+// into per-chunk buffers and written in order.
 int writeOFF(const std::string &path, const SimpleTriMesh &m) {
   FILE *fp = fopen(path.c_str(), "w");
   if (!fp) return FEM_ERR_IO;
   const bool col = m.colors.size() == m.points.size() && !m.colors.empty();
-  fprintf(fp, "%s\n%u %u 0\n", col ? "COFF" : "OFF", m.n_vertices(), m.n_faces());
-  for (uint i = 0; i < m.n_vertices(); i++) {
-    fprintf(fp, "%.9g %.9g %.9g", m.points[3 * i], m.points[3 * i + 1], m.points[3 * i + 2]);
-    if (col) fprintf(fp, " %d %d %d", m.colors[3 * i], m.colors[3 * i + 1], m.colors[3 * i + 2]);
-    fputc('\n', fp);
+  const size_t V = m.n_vertices(), F = m.n_faces(), N = V + F;
+  fprintf(fp, "%s\n%zu %zu 0\n", col ? "COFF" : "OFF", V, F);
+  const int T = N >= 200000 ? hostThreads() : 1;
+  const size_t chunk = 1u << 16;                     // records per buffer
+  bool ok = true;
+  for (size_t r0 = 0; r0 < N && ok; r0 += chunk * T) {
+    std::vector<std::string> out(T);
+    std::vector<std::thread> th;
+    auto work = [&](int t) {
+      const size_t b = std::min(N, r0 + chunk * t), e = std::min(N, b + chunk);
+      std::string &o = out[t];
+      o.reserve((e - b) * (col ? 56 : 44));
+      char line[160];
+      for (size_t r = b; r < e; r++) {
+        int n;
+        if (r < V) {
+          n = snprintf(line, sizeof line, "%.9g %.9g %.9g", m.points[3 * r], m.points[3 * r + 1], m.points[3 * r + 2]);
+          if (col) n += snprintf(line + n, sizeof line - n, " %d %d %d", m.colors[3 * r], m.colors[3 * r + 1], m.colors[3 * r + 2]);
+        } else {
+          const size_t f = r - V;
+          n = snprintf(line, sizeof line, "3 %u %u %u", m.faces[3 * f], m.faces[3 * f + 1], m.faces[3 * f + 2]);
+        }
+        line[n++] = '\n';
+        o.append(line, (size_t)n);
+      }
+    };
+    if (T == 1) work(0);
+    else {
+      for (int t = 0; t < T; t++) th.emplace_back(work, t);
+      for (auto &x : th) x.join();
+    }
+    for (int t = 0; t < T && ok; t++) ok = out[t].empty() || fwrite(out[t].data(), 1, out[t].size(), fp) == out[t].size();
   }
-  for (uint f = 0; f < m.n_faces(); f++)
-    fprintf(fp, "3 %u %u %u\n", m.faces[3 * f], m.faces[3 * f + 1], m.faces[3 * f + 2]);
-  return fclose(fp) == 0 ? FEM_OK : FEM_ERR_IO;
+  return (fclose(fp) == 0 && ok) ? FEM_OK : FEM_ERR_IO;
 }
 
 // ---------------------------------------------------------------- synthetic inputs

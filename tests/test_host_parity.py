@@ -217,3 +217,52 @@ def test_scanned_like_generator():
     assert np.array_equal(t0, ti) and np.array_equal(p0, pi)
     with pytest.raises(fa.FemError):
         fa.make_scanned_like(7, 0.1, seed=1, noise_amp=0.7)
+
+
+def test_off_reader_at_scale(tmp_path, monkeypatch):
+    """the threaded line-split path of the OFF reader (>= 200 000 records): same arrays as the
+    sequential parser, exact decimal conversion, comments / blank lines / CRLF / quads / colours,
+    and the fallback for records that span lines"""
+    pts, tri = fa.make_icosphere(100, 0.1)                       # 100 002 vertices + 200 000 faces
+    rgb = (np.arange(3 * len(pts)) % 251).astype(np.uint8).reshape(-1, 3)
+    path = str(tmp_path / "big.off")
+    fa.off_write(path, pts, tri, rgb)
+    text = open(path).read().split("\n")
+    expect_pts = np.array([[float(x) for x in l.split()[:3]] for l in text[2:2 + len(pts)]])
+    outs = []
+    for threads in ("4", "1"):
+        monkeypatch.setenv("FEM_HOST_THREADS", threads)
+        p2, t2, c2 = fa.off_read(path)
+        assert np.array_equal(p2, expect_pts) and np.array_equal(t2, tri) and np.array_equal(c2, rgb)
+        outs.append(p2)
+    # decorated variant: comments, blank lines, CRLF, float colours, one quad, face colours
+    monkeypatch.setenv("FEM_HOST_THREADS", "4")
+    V = len(pts)
+    lines = ["COFF", "# made by test", "%d %d 0" % (V, len(tri) - 1), ""]
+    for i in range(V):
+        lines.append("%r %r %r %.6f %.6f %.6f 1.0\r" % (float(pts[i, 0]), float(pts[i, 1]), float(pts[i, 2]), rgb[i, 0] / 255,
+                                                        rgb[i, 1] / 255, rgb[i, 2] / 255))
+        if i % 30011 == 0:
+            lines.append("   # a comment between records")
+    a, b, c = (int(x) for x in tri[0])
+    d = next(int(x) for x in tri[1] if int(x) not in (a, b, c))
+    lines.append("4 %d %d %d %d  255 0 0" % (a, b, c, d))       # replaces the first two triangles
+    for f in tri[2:]:
+        lines.append("3 %d %d %d" % tuple(f))
+    path2 = str(tmp_path / "decorated.off")
+    open(path2, "w").write("\n".join(lines) + "\n")
+    p3, t3, c3 = fa.off_read(path2)
+    assert np.array_equal(p3, pts) and np.array_equal(c3, rgb)   # repr round-trips doubles exactly
+    assert np.array_equal(t3[:2], [[a, b, c], [a, c, d]]) and np.array_equal(t3[2:], tri[2:])
+    # records spanning lines: the sequential token parser takes over
+    lines2 = text[:2] + [w for l in text[2:2 + V] for w in (" ".join(l.split()[:2]), " ".join(l.split()[2:]))] + text[2 + V:]
+    path3 = str(tmp_path / "split.off")
+    open(path3, "w").write("\n".join(lines2))
+    p4, t4, c4 = fa.off_read(path3)
+    assert np.array_equal(p4, expect_pts) and np.array_equal(t4, tri) and np.array_equal(c4, rgb)
+    # a bad index in the middle of a big file is an error, not a crash
+    bad = list(text)
+    bad[2 + V + 150000] = "3 0 1 %d" % V
+    open(path3, "w").write("\n".join(bad))
+    with pytest.raises(fa.FemError):
+        fa.off_read(path3)
