@@ -217,13 +217,17 @@ class Mesh:
         _check(lib.fem_compute_vertex_gradients_cpu(self.h, _ptr(fg, f64p), _ptr(out, f64p)))
         return out
 
-    def partition_vertices(self, n):
+    def partition_vertices(self, n, method="rcb"):
+        """vertex -> part id; method "rcb" (coordinate bisection) or "graph" (graph bisection)"""
         npart = np.empty(self.V, np.int64)
-        _check(lib.fem_partition_vertices(self.h, C.c_int(n), _ptr(npart, i64p)))
+        fn = {"rcb": lib.fem_partition_vertices, "graph": lib.fem_partition_vertices_graph}[method]
+        _check(fn(self.h, C.c_int(n), _ptr(npart, i64p)))
         return npart
 
-    def partition(self, n, npart=None):
+    def partition(self, n, npart=None, method="rcb"):
         """-> Partition (perm_v, perm_f, node_parts, element_parts, ordered Mesh, cut)"""
+        if npart is None and method != "rcb":
+            npart = self.partition_vertices(n, method)
         perm_v, perm_f = np.empty(self.V, np.int64), np.empty(self.F, np.int64)
         node_parts, element_parts = np.empty(n + 1, np.uint32), np.empty(n + 2, np.uint32)
         oh = vp()

@@ -136,6 +136,12 @@ int fem_partition_vertices(const fem_mesh *m, int n, int64_t *npart) {
   return rc == FEM_OK ? rc : fail(rc, "fem_partition_vertices: need 1 <= n <= V");
 }
 
+int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart) {
+  if (!m || !npart) return fail(FEM_ERR_INVALID, "fem_partition_vertices_graph: null");
+  int rc = fem::partitionVerticesGraph(m->mesh, n, npart);
+  return rc == FEM_OK ? rc : fail(rc, "fem_partition_vertices_graph: need 1 <= n <= V and a mesh with topology");
+}
+
 int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,
                         int64_t *perm_f, fem_uint *node_parts, fem_uint *element_parts,
                         fem_mesh **ordered) {

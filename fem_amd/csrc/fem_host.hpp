@@ -84,7 +84,8 @@ int partition(const SimpleTriMesh &originalMesh, SimpleTriMesh *orderedMesh, uin
               uint **element_parts, int n);
 
 // pieces of the above (partitioning_common.cpp:32-176)
-int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart);
+int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart);          // coordinate bisection
+int partitionVerticesGraph(const SimpleTriMesh &m, int n, int64_t *npart);     // graph bisection (needs topology)
 void faceParts(const SimpleTriMesh &m, const int64_t *npart, int n, int64_t *epart);
 int createOrderArray(uint *parts, int64_t *part, int64_t N, int n);
 void reorderMesh(const SimpleTriMesh &original, SimpleTriMesh *ordered, const int64_t *npart,

@@ -50,6 +50,119 @@ struct Rcb {
 };
 }  // namespace
 
+// Recursive graph bisection on the vertex graph (coordinate-free: for surfaces whose Euclidean
+// neighbours are geodesically far apart -- folds, thin sheets -- where a coordinate split makes
+// disconnected parts).  Bisect(S, nl): breadth-first order of the induced subgraph from a
+// pseudo-peripheral vertex (two sweeps; further components appended in id order), first nl vertices
+// left; then boundary refinement by pairwise swaps (largest gain first, ties by id) so that the
+// sizes stay exact.  Same recursion/numbering and the same balance as the coordinate split;
+// deterministic; O(E log n).
+namespace {
+struct GraphBisect {
+  const SimpleTriMesh &m;
+  int64_t *npart;
+  std::vector<uint32_t> ids, order, side;          // side[v]: stamp << 1 | (0 left, 1 right) during a bisection
+  std::vector<uint32_t> seen;
+  uint32_t stamp = 0;
+
+  // BFS of the subgraph {v : side[v] >> 1 == tag} from `root`, appending to order; returns last vertex
+  void bfs(uint32_t root, uint32_t tag, uint32_t visit) {
+    size_t head = order.size();
+    order.push_back(root); seen[root] = visit;
+    while (head < order.size()) {
+      const uint32_t v = order[head++];
+      for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+        const uint32_t u = m.col[e];
+        if ((side[u] >> 1) == tag && seen[u] != visit) { seen[u] = visit; order.push_back(u); }
+      }
+    }
+  }
+  uint32_t nextVisit() { return ++stamp; }
+
+  void run(size_t b, size_t e, int p0, int np) {
+    while (np > 1) {
+      const int nl = np / 2;
+      const size_t cnt = e - b, nleft = (size_t)(cnt * (uint64_t)nl / (uint64_t)np);
+      const uint32_t tag = nextVisit();
+      for (size_t i = b; i < e; i++) side[ids[i]] = tag << 1;
+      // pseudo-peripheral start: BFS from the lowest id, restart from the last vertex reached
+      uint32_t root = *std::min_element(ids.begin() + b, ids.begin() + e);
+      for (int sweep = 0; sweep < 2; sweep++) {
+        order.clear();
+        bfs(root, tag, nextVisit());
+        root = order.back();
+      }
+      order.clear();
+      const uint32_t visit = nextVisit();
+      bfs(root, tag, visit);
+      if (order.size() < cnt) {                     // disconnected subset: remaining components, lowest id first
+        std::vector<uint32_t> rest(ids.begin() + b, ids.begin() + e);
+        std::sort(rest.begin(), rest.end());
+        for (uint32_t v : rest)
+          if (seen[v] != visit) bfs(v, tag, visit);
+      }
+      for (size_t i = 0; i < cnt; i++) side[order[i]] = (tag << 1) | (i >= nleft ? 1u : 0u);
+      refine(tag);
+      size_t l = b, r = b + nleft;
+      for (size_t i = 0; i < cnt; i++) {
+        const uint32_t v = order[i];
+        if (side[v] & 1u) ids[r++] = v; else ids[l++] = v;
+      }
+      run(b, b + nleft, p0, nl);
+      b += nleft; p0 += nl; np -= nl;
+    }
+    for (size_t i = b; i < e; i++) npart[ids[i]] = p0;
+  }
+
+  // gain of moving v to the other side = (neighbours there) - (neighbours here), within the subset
+  int gain(uint32_t v, uint32_t tag) const {
+    int g = 0;
+    const uint32_t sv = side[v];
+    for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+      const uint32_t su = side[m.col[e]];
+      if ((su >> 1) == tag) g += su != sv ? 1 : -1;
+    }
+    return g;
+  }
+  void refine(uint32_t tag) {
+    std::vector<std::pair<int, uint32_t>> L, R;
+    for (int pass = 0; pass < 6; pass++) {
+      L.clear(); R.clear();
+      for (uint32_t v : order) {
+        bool bnd = false;
+        for (int e = m.rowptr[v]; e < m.rowptr[v + 1] && !bnd; e++) bnd = side[m.col[e]] == (side[v] ^ 1u);
+        if (!bnd) continue;
+        const int g = gain(v, tag);
+        ((side[v] & 1u) ? R : L).push_back(std::make_pair(-g, v));
+      }
+      std::sort(L.begin(), L.end()); std::sort(R.begin(), R.end());
+      size_t swaps = 0;
+      for (size_t i = 0; i < std::min(L.size(), R.size()); i++) {
+        const uint32_t a = L[i].second, c = R[i].second;
+        // gains may have changed through earlier swaps of this pass: recompute
+        int g = gain(a, tag) + gain(c, tag);
+        for (int e = m.rowptr[a]; e < m.rowptr[a + 1]; e++) if (m.col[e] == c) { g -= 2; break; }
+        if (g <= 0) { if (-L[i].first - R[i].first <= 0) break; else continue; }
+        side[a] ^= 1u; side[c] ^= 1u;
+        swaps++;
+      }
+      if (swaps == 0) break;
+    }
+  }
+};
+}  // namespace
+
+int partitionVerticesGraph(const SimpleTriMesh &m, int n, int64_t *npart) {
+  const int64_t V = m.n_vertices();
+  if (n < 1 || V < n || m.H == 0) return FEM_ERR_INVALID;
+  GraphBisect g{m, npart, {}, {}, {}, {}, 0};
+  g.ids.resize((size_t)V); g.side.assign((size_t)V, 0); g.seen.assign((size_t)V, 0);
+  g.order.reserve((size_t)V);
+  for (int64_t i = 0; i < V; i++) g.ids[i] = (uint32_t)i;
+  g.run(0, (size_t)V, 0, n);
+  return FEM_OK;
+}
+
 int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart) {
   const int64_t V = m.n_vertices();
   if (n < 1 || V < n) return FEM_ERR_INVALID;

@@ -136,6 +136,11 @@ int fem_partition(const fem_mesh *original, int n, int64_t *perm_v, int64_t *per
 /* The stage METIS_PartMeshDual occupied (partitioning_common.cpp:51-58):
  * vertex -> part id in [0,n). */
 int fem_partition_vertices(const fem_mesh *m, int n, int64_t *npart);
+/* Same stage, coordinate-free: recursive bisection of the vertex graph (breadth-first halves from
+ * a pseudo-peripheral vertex + pairwise boundary refinement); same balance (part sizes differ by
+ * at most one), same hierarchical numbering, deterministic.  For surfaces where a coordinate
+ * split makes disconnected parts (folds, thin sheets); feed the result to fem_partition_apply. */
+int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart);
 /* The deterministic stage after it (partitioning_common.cpp:78-176), given any
  * npart[]: same outputs as fem_partition. */
 int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,

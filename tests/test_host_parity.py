@@ -266,3 +266,53 @@ def test_off_reader_at_scale(tmp_path, monkeypatch):
     open(path3, "w").write("\n".join(bad))
     with pytest.raises(fa.FemError):
         fa.off_read(path3)
+
+
+def _components_per_part(mesh, npart, n):
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import connected_components
+    topo = mesh.topology()
+    rp, col = topo["rowptr"], topo["col"].astype(np.int64)
+    row = np.repeat(np.arange(mesh.V), np.diff(rp))
+    keep = npart[row] == npart[col]
+    A = sp.csr_matrix((np.ones(keep.sum(), np.int8), (row[keep], col[keep])), shape=(mesh.V, mesh.V))
+    ncomp, lab = connected_components(A, directed=False)
+    return np.array([len(np.unique(lab[npart == p])) for p in range(n)])
+
+
+def test_graph_partitioner():
+    """coordinate-free graph bisection: balanced, deterministic, hierarchical ids,
+    goes through the same R1-R3 contract; on a folded sheet -- two layers 1e-3 apart -- the
+    coordinate split makes disconnected parts and a larger cut, the graph split does not"""
+    pts, tri = fa.make_icosphere(20, 0.1)
+    m = fa.Mesh(pts, tri)
+    n = 13
+    g1, g2 = m.partition_vertices(n, "graph"), m.partition_vertices(n, "graph")
+    assert np.array_equal(g1, g2) and g1.min() == 0 and g1.max() == n - 1
+    sizes = np.bincount(g1, minlength=n)
+    assert sizes.max() - sizes.min() <= 1
+    assert (_components_per_part(m, g1, n) == 1).all()
+    part = m.partition(n, method="graph")
+    pv, pf, nparts, eparts, pts_o, tri_o = ol.partition_apply(m.V, pts, tri, g1, n)
+    assert np.array_equal(part.perm_v, pv) and np.array_equal(part.ordered.tri, tri_o)
+    # quality in the range of the coordinate split on a geometric mesh
+    assert part.cut <= 1.15 * m.partition(n).cut
+    # hierarchical numbering: parts [0, n/2) and [n/2, n) are each one connected region
+    half = (g1 >= n // 2).astype(np.int64)
+    assert (_components_per_part(m, half, 2) == 1).all()
+    # folded sheet
+    nx, ny, h = 24, 160, 0.1
+    sp_, st_ = fa.make_strip(nx, ny, h)
+    iy = np.arange(nx * ny) % ny
+    fold = sp_.copy()
+    s = h / np.sqrt(2.0)
+    yy = np.where(iy < ny // 2, iy, ny - 1 - iy) * s
+    fold[:, 1], fold[:, 2] = yy, yy + np.where(iy < ny // 2, 0.0, 1e-3)
+    fm = fa.Mesh(fold, st_)
+    k = 16
+    rcb, gr = fm.partition_vertices(k, "rcb"), fm.partition_vertices(k, "graph")
+    assert (_components_per_part(fm, gr, k) == 1).all()
+    assert (_components_per_part(fm, rcb, k) > 1).any()
+    assert fm.partition(k, npart=gr).cut < 0.8 * fm.partition(k, npart=rcb).cut
+    with pytest.raises(fa.FemError):
+        m.partition_vertices(m.V + 1, "graph")
