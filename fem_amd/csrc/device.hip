@@ -210,7 +210,19 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
 // vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
 // ---------------------------------------------------------------------------
-template <typename T, int TPB, int R, int W, int MINW, bool X>
+// streaming (read-once) 16/32-byte load: keeps the operator rows from evicting the state lines in L2
+__device__ __forceinline__ float4 ntload(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double4 ntload(const double4 *p) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p) + 1);
+  return make_double4(a.x, a.y, b.x, b.y);
+}
+
+template <typename T, int TPB, int R, int W, int MINW, bool X, int PRO>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
@@ -243,17 +255,35 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   // ghost ids, then the state gathers; the first wait is the one in front of the LDS writes.
   T4 cf[R][W];
   uint ix[R][W / 2];
+  constexpr int SU = 4;                                  // state slots per thread per pass
+  uint gi[SU];
+  auto loadGhostIds = [&](uint i0) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      const uint g = (i >= n0 && i < mk) ? i - n0 : 0;   // ghost[] carries one pad element
+      gi[u] = PRO == 3 ? __builtin_nontemporal_load(&ghost[goff + g]) : ghost[goff + g];
+    }
+  };
+  // Issue order = completion order (one in-order counter per wave): the ghost ids go first, so
+  // the dependent state gathers can leave while the operator rows are still streaming in.
+  // PRO (FEM_TILE_PROLOGUE, same-box A/B on the 16M sphere): 0 ids after the operator 219.0;
+  // 1 ids first 220.2; 2 + operator rows as nontemporal loads 222.9; 3 + index streams
+  // nontemporal 224.6-228.7 G DOF-it/s (the read-once streams stop evicting the state, which
+  // is the only data with reuse between tiles and launches).
+  if (PRO >= 1) loadGhostIds(0);
 #pragma unroll
   for (int q = 0; q < R; q++) {
     const uint r = min(t + TPB * q, rpad - 1);         // rows in [rows, rpad) are zero padding
 #pragma unroll
-    for (int w = 0; w < W; w++) cf[q][w] = tcoef[w * rpad + r];
+    for (int w = 0; w < W / 2; w++)                      // ids < 4096: both halves scale
+      ix[q][w] = (PRO == 3 ? __builtin_nontemporal_load(&tidx[w * rpad + r]) : tidx[w * rpad + r]) * (uint)sizeof(T2);
+  }
 #pragma unroll
-    for (int w = 0; w < W / 2; w++) ix[q][w] = tidx[w * rpad + r] * (uint)sizeof(T2);   // ids < 4096: both halves scale
-    if constexpr (IXL) {
+  for (int q = 0; q < R; q++) {
+    const uint r = min(t + TPB * q, rpad - 1);
 #pragma unroll
-      for (int w = 0; w < W / 2; w++) xs_ix[w * (TPB * R) + t + TPB * q] = ix[q][w];
-    }
+    for (int w = 0; w < W; w++) cf[q][w] = PRO >= 2 ? ntload(&tcoef[w * rpad + r]) : tcoef[w * rpad + r];
   }
   if (X && xcnt) {                                       // tile-uniform
     for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
@@ -262,20 +292,19 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
       xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
     }
   }
-  constexpr int SU = 4;                                  // state slots per thread per pass
   for (uint i0 = 0; i0 < mk; i0 += SU * TPB) {
-    uint gi[SU];
     T2 sv[SU];
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const uint i = i0 + t + TPB * u;
-      const uint g = (i >= n0 && i < mk) ? i - n0 : 0;   // ghost[] carries one pad element
-      gi[u] = ghost[goff + g];
-    }
+    if (PRO < 1 || i0 > 0) loadGhostIds(i0);
 #pragma unroll
     for (int u = 0; u < SU; u++) {
       const uint i = i0 + t + TPB * u;
       sv[u] = src[i < n0 ? base + i : gi[u]];
+    }
+    if (IXL && i0 == 0) {
+#pragma unroll
+      for (int q = 0; q < R; q++)
+#pragma unroll
+        for (int w = 0; w < W / 2; w++) xs_ix[w * (TPB * R) + t + TPB * q] = ix[q][w];
     }
 #pragma unroll
     for (int u = 0; u < SU; u++) {
@@ -781,7 +810,9 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   // One variant for regular and irregular meshes: the build with the wide-row loop measured 4 %
   // FASTER on the regular 16M sphere than the one without it (same-box A/B, 213.5 vs 204.3 G
   // DOF-it/s), so the X = false instantiation is not dispatched.
-  auto kern = tile_step_kernel<T, TPB, R, kTileW, MINW, true>;
+  static const int pro = getenv("FEM_TILE_PROLOGUE") ? atoi(getenv("FEM_TILE_PROLOGUE")) : 3;   // tuning knob; 3 measured best
+  auto kern = pro == 3 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 3> : pro == 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 2>
+                       : (pro == 1 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, true, 0>);
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
                      (size_t)TPB * R * 4 * (1 + kTileW / 2);
   if (lds > 64 * 1024) {
