@@ -168,7 +168,19 @@ __device__ __forceinline__ typename Vec<T>::t2 reaction_update(typename Vec<T>::
   return o;
 }
 
-template <typename T>
+// streaming (read-once) 16/32-byte load: keeps the operator rows from evicting the state lines in L2
+__device__ __forceinline__ float4 ntload(const float4 *p) {
+  typedef float v4f __attribute__((ext_vector_type(4)));
+  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double4 ntload(const double4 *p) {
+  typedef double v2d __attribute__((ext_vector_type(2)));
+  const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p) + 1);
+  return make_double4(a.x, a.y, b.x, b.y);
+}
+
+template <typename T, bool NT>
 __global__ __launch_bounds__(256) void sell_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ slice_off, const uint *__restrict__ idx,
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
   T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
 #pragma unroll 2
   for (uint e = off + lane; e < end; e += 64) {
-    const uint j = idx[e];
-    const T4 c = coef[e];
+    const uint j = NT ? __builtin_nontemporal_load(&idx[e]) : idx[e];     // read-once streams: do not evict the state
+    const T4 c = NT ? ntload(&coef[e]) : coef[e];
     const T2 f = src[j];
     const T dn = f.x - s.x, dc = f.y - s.y;
     lapn += c.x * dn; lapc += c.x * dc;
@@ -210,18 +222,6 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
 // vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
 // ---------------------------------------------------------------------------
-// streaming (read-once) 16/32-byte load: keeps the operator rows from evicting the state lines in L2
-__device__ __forceinline__ float4 ntload(const float4 *p) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ double4 ntload(const double4 *p) {
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p) + 1);
-  return make_double4(a.x, a.y, b.x, b.y);
-}
-
 template <typename T, int TPB, int R, int W, int MINW, bool X, int PRO>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
@@ -1257,12 +1257,13 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
                        1.0 / (1.0 + p->base_n)};
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
+    static const bool nt = !(getenv("FEM_SELL_NT") && atoi(getenv("FEM_SELL_NT")) == 0);
     if (p->precision == FEM_PREC_F32)
-      hipLaunchKernelGGL(sell_step_kernel<float>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
+      hipLaunchKernelGGL((nt ? sell_step_kernel<float, true> : sell_step_kernel<float, false>), dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
                          p->V, p->nslices, p->nblocks, mf);
     else
-      hipLaunchKernelGGL(sell_step_kernel<double>, dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
+      hipLaunchKernelGGL((nt ? sell_step_kernel<double, true> : sell_step_kernel<double, false>), dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const double2 *)src, (double2 *)dst, p->slice_off.p, p->idx.p, (const double4 *)p->coef,
                          p->V, p->nslices, p->nblocks, md);
     p->cur ^= 1;

@@ -156,20 +156,23 @@ def test_native_plan_ragged_sizes():
         assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
 
 
-def test_native_plan_full_size_properties():
-    """1M-vertex sphere (BASELINE config 2 size): size-independent properties.
+@pytest.mark.parametrize("ksteps", [0, 4])
+def test_native_plan_full_size_properties(ksteps):
+    """1M-vertex sphere (BASELINE config 2 size), sliced-ELL and fused plans: size-independent
+    properties.
     (i) a constant state is a fixed point of diffusion/chemotaxis: with r = 0 one step changes
         n by exactly 0 and c only through S*(n/(1+n) - c) = 0;
     (ii) determinism: two runs from the same state agree bit for bit (no atomics);
-    (iii) sampled rows of the fp32 result match the fp64 plan within tolerance."""
+    (iii) the fp32 result matches the fp64 plan within tolerance;
+    (iv) format(): extrema and colours of the result agree with numpy on the downloaded state."""
     pts, tri = fa.make_icosphere(320, 0.1)
     mesh = fa.Mesh(pts, tri)
-    part = mesh.partition(4096)
+    part = mesh.partition(4096 if ksteps == 0 else mesh.V // 620)
     om = part.ordered
     om.init_stats(fa.PREC_F64)
     dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
     model = fa.default_model()
-    plan = fa.Plan(om, fa.PREC_F32)
+    plan = fa.Plan(om, fa.PREC_F32, part=part, ksteps=ksteps)
     # (i)
     m0 = fa.default_model()
     m0.r = 0.0
@@ -188,11 +191,16 @@ def test_native_plan_full_size_properties():
         plan.run(20, dt, model)
         outs.append(plan.get_state())
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
-    plan64 = fa.Plan(om, fa.PREC_F64)
+    plan64 = fa.Plan(om, fa.PREC_F64, part=part, ksteps=ksteps)
     plan64.set_state(n0.astype(np.float32), c0.astype(np.float32))
     plan64.run(20, dt, model)
     n64, c64 = plan64.get_state()
     assert rel_l2(outs[0][0], n64) <= TOL_F32 and rel_l2(outs[0][1], c64) <= TOL_F32
+    # (iv)
+    rgba, rgb, lo, hi = plan.format()
+    n = outs[0][0]
+    assert abs(lo - n.min()) <= 1e-6 and abs(hi - n.max()) <= 1e-6
+    assert np.abs(rgba[:, 0] - (n - n.min()) / (n.max() - n.min())).max() <= 1e-4
 
 
 @pytest.mark.parametrize("make,nparts,ksteps,steps", [
