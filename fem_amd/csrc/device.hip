@@ -1,11 +1,11 @@
-// device.hip -- gfx950 kernels and the device half of the C-ABI.
-//
-//   ref_step_kernel  : the reference's fused time step on the reference's own
-//                      padded SoA layout (what `step` launches; reference
-//                      src/FEM_common.cu:82-180), one workgroup per partition.
-//   sell_step_kernel : the native time step on the sliced-ELL layout with
-//                      folded gradient coefficients (pack.cpp), one wave64 per
-//                      64-row slice, no atomics, no LDS.
+// device.hip -- the device half of the C-ABI: plans, the reference device harness, launches.
+// The gfx950 kernels live in kernels_*.hpp (same translation unit):
+//   kernels_step.hpp     ref_step_kernel (the reference's fused time step on its own padded SoA
+//                        layout, what `step` launches; src/FEM_common.cu:82-180),
+//                        sell_step_kernel (sliced ELL, one wave64 per 64-row slice),
+//                        tile_step_kernel (k fused steps per launch, rows in registers, state in LDS)
+//   kernels_assembly.hpp operator assembly from the vertex positions, per-face records, deformation
+//   kernels_output.hpp   min/max + colour map (format()), halo pack
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -43,648 +43,10 @@ int fail(int status, const char *what, hipError_t e = hipSuccess) {
 
 struct ModelD { double nMax, D, r, alpha, S; };
 
-// ---------------------------------------------------------------------------
-// Reference-layout step (FEM_common.cu:82-166).  Differences from the reference
-// kernel, none of them in the arithmetic: all loops are block-strided, so no
-// thread leaves before a barrier and a partition may hold more faces or
-// vertices than the block has threads (the reference returns early at :99-100
-// and :138-139); the double accumulator uses the LDS f64 add instead of a CAS
-// loop (:15-31).
-// LDS: wg[size] double, then nvGrads[3*size], cvGrads[3*size] float = 32 B/vertex.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ref_step_kernel(
-    const double2 *__restrict__ fn_src, double2 *__restrict__ fn_dst, const uint *__restrict__ fv,
-    const double *__restrict__ fv_weights, uint fv_pitch, uint fvw_pitch, const uint *__restrict__ nbr,
-    const double *__restrict__ vtxW, uint vw_pitch, const double *__restrict__ vertex_weights,
-    uint vv_pitch, uint vws_pitch, uint vv_size, const float4 *__restrict__ grads, uint he_pitch,
-    const uint *__restrict__ vertex_parts, const uint *__restrict__ block_face_count, double dt,
-    ModelD m) {
-  extern __shared__ double s_mem[];
-  const uint p = blockIdx.x;
-  const uint base = vertex_parts[p];
-  const uint size = vertex_parts[p + 1] - base;
-  double *s_wg = s_mem;
-  float *s_nv = reinterpret_cast<float *>(s_wg + size);
-  float *s_cv = s_nv + 3 * size;
-
-  for (uint i = threadIdx.x; i < size; i += blockDim.x) {
-    s_wg[i] = 0.0;
-    s_nv[3 * i] = s_nv[3 * i + 1] = s_nv[3 * i + 2] = 0.0f;
-    s_cv[3 * i] = s_cv[3 * i + 1] = s_cv[3 * i + 2] = 0.0f;
-  }
-  __syncthreads();
-
-  /* face gradients, scattered to the owned corners */
-  const uint nfaces = block_face_count[p];
-  const size_t fvb = (size_t)p * 3 * fv_pitch, fwb = (size_t)p * 3 * fvw_pitch, heb = (size_t)p * 2 * he_pitch;
-  for (uint t = threadIdx.x; t < nfaces; t += blockDim.x) {
-    const uint i0 = fv[fvb + t], i1 = fv[fvb + fv_pitch + t], i2 = fv[fvb + 2 * (size_t)fv_pitch + t];
-    const double2 v1 = fn_src[i2], a = fn_src[i0], b = fn_src[i1];
-    const float d12x = (float)(a.x - v1.x), d12y = (float)(a.y - v1.y);
-    const float d13x = (float)(b.x - v1.x), d13y = (float)(b.y - v1.y);
-    const float4 g12 = grads[heb + t], g13 = grads[heb + he_pitch + t];
-    const float nvx = g12.x * d12x + g13.x * d13x, nvy = g12.y * d12x + g13.y * d13x, nvz = g12.z * d12x + g13.z * d13x;
-    const float cvx = g12.x * d12y + g13.x * d13y, cvy = g12.y * d12y + g13.y * d13y, cvz = g12.z * d12y + g13.z * d13y;
-    const uint idx[3] = {i0, i1, i2};
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const uint li = idx[j] - base;              // unsigned wrap makes "below base" large
-      if (li < size) {
-        const double weight = fv_weights[fwb + (size_t)j * fvw_pitch + t];
-        atomicAdd(&s_nv[3 * li], (float)(nvx * weight));
-        atomicAdd(&s_nv[3 * li + 1], (float)(nvy * weight));
-        atomicAdd(&s_nv[3 * li + 2], (float)(nvz * weight));
-        atomicAdd(&s_cv[3 * li], (float)(cvx * weight));
-        atomicAdd(&s_cv[3 * li + 1], (float)(cvy * weight));
-        atomicAdd(&s_cv[3 * li + 2], (float)(cvz * weight));
-        unsafeAtomicAdd(&s_wg[li], weight);
-      }
-    }
-  }
-  __syncthreads();
-
-  /* laplacian, vertex gradients, update */
-  const size_t nb = (size_t)p * (vv_size + 1) * vv_pitch, wb = (size_t)p * vv_size * vws_pitch;
-  for (uint t = threadIdx.x; t < size; t += blockDim.x) {
-    const uint i = base + t;
-    const double2 s = fn_src[i];
-    const double vW = vtxW[(size_t)p * vw_pitch + t];
-    double lx = s.x * vW, ly = s.y * vW;
-    const uint end = nbr[nb + t];
-    for (uint j = 0; j < end; j++) {
-      const uint nIdx = nbr[nb + (size_t)vv_pitch * (j + 1) + t];
-      const double hW = vertex_weights[wb + (size_t)vws_pitch * j + t];
-      const double2 f = fn_src[nIdx];
-      lx += f.x * hW; ly += f.y * hW;
-    }
-    double dotP = 0;
-    const double wg = s_wg[t];
-    if (wg > 0) {
-      const float w = (float)wg;
-      dotP = (s_nv[3 * t] / w) * (s_cv[3 * t] / w) + (s_nv[3 * t + 1] / w) * (s_cv[3 * t + 1] / w) +
-             (s_nv[3 * t + 2] / w) * (s_cv[3 * t + 2] / w);
-    }
-    const double dauN = m.D * lx - m.alpha * s.x * ly - m.alpha * dotP + m.S * m.r * s.x * (m.nMax - s.x);
-    const double dauC = ly + m.S * (s.x / (1 + s.x) - s.y);
-    double2 o;
-    o.x = dt * dauN + s.x > 0 ? dt * dauN + s.x : 0.0;
-    o.y = dt * dauC + s.y > 0 ? dt * dauC + s.y : 0.0;
-    fn_dst[i] = o;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Native step.  One wave64 per slice; entry (k, lane) of a slice lives at
-// slice_off + k*64 + lane, so every operator load is one fully coalesced
-// 256-B (idx) or 1-KiB (coef, fp32) wave access; neighbour state is gathered
-// from global memory (L1/L2-resident: a slice's neighbours are a few KB).
-// Workgroups are renumbered so that consecutive slices run on one XCD and share
-// its L2 (workgroups are dealt round-robin over the 8 XCDs).
-// Algorithmic bytes per vertex (fp32, valence 6): 6*(4+16) operator + 8 state
-// read + 8 state write = 136 B (+ gathers served on chip).
-// ---------------------------------------------------------------------------
-template <typename T> struct Vec;
-template <> struct Vec<float> { typedef float2 t2; typedef float4 t4; };
-template <> struct Vec<double> { typedef double2 t2; typedef double4 t4; };
-
-// bn = base value the stored n is a deviation from; cden = 1/(1+bn); nMaxOff = nMax - bn
-template <typename T> struct ModelT { T nMaxOff, D, r, alpha, S, dt, bn, cden; };
-
-// Reaction + explicit Euler + clamp (FEM_common.cu:153-165) on deviation-form state.
-// The buffers hold deviations (n - bn, c - bn/(1+bn)) from the homogeneous state: differences
-// are unchanged, n(nMax - n) = n((nMax - bn) - dev) and n/(1+n) - c = dev_n/((1+n)(1+bn)) - dev_c
-// are exact rewrites, and the update no longer rounds at the magnitude of n itself.
-template <typename T>
-__device__ __forceinline__ typename Vec<T>::t2 reaction_update(typename Vec<T>::t2 s, T lapn, T lapc, T gnx, T gny,
-                                                               T gnz, T gcx, T gcy, T gcz, const ModelT<T> &m) {
-  const T n = m.bn + s.x;
-  const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
-  const T dauN = m.D * lapn - m.alpha * n * lapc - m.alpha * dotP + m.S * m.r * n * (m.nMaxOff - s.x);
-  const T dauC = lapc + m.S * (s.x * m.cden / (1 + n) - s.y);
-  const T un = m.dt * dauN + s.x, uc = m.dt * dauC + s.y;
-  typename Vec<T>::t2 o;
-  o.x = un + m.bn > 0 ? un : -m.bn;                 // max(0, n) of FEM_common.cu:164-165
-  o.y = uc + m.bn * m.cden > 0 ? uc : -(m.bn * m.cden);
-  return o;
-}
-
-// streaming (read-once) 16/32-byte load: keeps the operator rows from evicting the state lines in L2
-__device__ __forceinline__ float4 ntload(const float4 *p) {
-  typedef float v4f __attribute__((ext_vector_type(4)));
-  const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(p));
-  return make_float4(v.x, v.y, v.z, v.w);
-}
-__device__ __forceinline__ double4 ntload(const double4 *p) {
-  typedef double v2d __attribute__((ext_vector_type(2)));
-  const v2d a = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p)), b = __builtin_nontemporal_load(reinterpret_cast<const v2d *>(p) + 1);
-  return make_double4(a.x, a.y, b.x, b.y);
-}
-
-template <typename T, bool NT>
-__global__ __launch_bounds__(256) void sell_step_kernel(
-    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
-    const uint *__restrict__ slice_off, const uint *__restrict__ idx,
-    const typename Vec<T>::t4 *__restrict__ coef, uint V, uint nslices, uint nblocks, ModelT<T> m) {
-  typedef typename Vec<T>::t2 T2;
-  typedef typename Vec<T>::t4 T4;
-  // bijective XCD remap: blocks b, b+8, b+16, ... (one XCD) get consecutive slices
-  const uint b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7u, x = b & 7u;
-  const uint lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-  const uint slice = lb * 4 + (threadIdx.x >> 6);
-  if (slice >= nslices) return;
-  const uint lane = threadIdx.x & 63u;
-  const uint off = __builtin_amdgcn_readfirstlane(slice_off[slice]);
-  const uint end = __builtin_amdgcn_readfirstlane(slice_off[slice + 1]);
-  const uint v = slice * 64 + lane;
-  const uint vs = v < V ? v : V - 1;
-  const T2 s = src[vs];
-  T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
-#pragma unroll 2
-  for (uint e = off + lane; e < end; e += 64) {
-    const uint j = NT ? __builtin_nontemporal_load(&idx[e]) : idx[e];     // read-once streams: do not evict the state
-    const T4 c = NT ? ntload(&coef[e]) : coef[e];
-    const T2 f = src[j];
-    const T dn = f.x - s.x, dc = f.y - s.y;
-    lapn += c.x * dn; lapc += c.x * dc;
-    gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
-    gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
-  }
-  const T2 o = reaction_update<T>(s, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
-  if (v < V) dst[v] = o;
-}
-
-// ---------------------------------------------------------------------------
-// Fused k-step kernel.  One workgroup per tile (pack.cpp:packTileLayout): the tile's owned rows
-// plus k rings of neighbours are staged in LDS (two ping-pong buffers of m[k] pairs), the
-// operator rows of the first m[k-1] local rows are loaded ONCE into registers (thread t holds rows
-// t, t+TPB, ...: R rows x W entries x (float4 coef + 16-bit local column id)), and the workgroup
-// takes up to k time steps before writing its owned rows back: step s recomputes rows
-// [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
-// vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
-// ---------------------------------------------------------------------------
-template <typename T, int TPB, int R, int W, int MINW, bool X, int PRO>
-__global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
-    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
-    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
-    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
-    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
-  typedef typename Vec<T>::t2 T2;
-  typedef typename Vec<T>::t4 T4;
-  extern __shared__ __align__(16) unsigned char tile_smem[];
-  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
-  const uint tile = tile0 + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);   // tiles [tile0, tile0 + ntiles)
-  const uint *mt = meta + 16 * (size_t)tile;
-  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], k = mt[4];
-  const uint n0 = mt[5], mk = mt[5 + k];
-  T2 *cur = reinterpret_cast<T2 *>(tile_smem);
-  T2 *nxt = cur + maxLocal;
-  // rows wider than W (irregular meshes): entries W, W+1, ... of all rows of the tile, in LDS
-  T4 *xs_coef = reinterpret_cast<T4 *>(nxt + maxLocal);          // maxLocal is even: 16-B aligned
-  uint *xs_off = reinterpret_cast<uint *>(xs_coef + maxExtra);
-  uint *xs_info = xs_off + maxExtra;                             // [T*R] rows of the register tile
-  uint *xs_ix = xs_info + TPB * R;                               // X: the packed column offsets live here, not in VGPRs
-  constexpr bool IXL = true;                             // packed column offsets in LDS (frees W/2*R VGPRs)
-  const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // X = false: plan without wide rows
-  const uint t = threadIdx.x;
-
-  // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
-  const T4 *__restrict__ tcoef = coef + roff;
-  const uint *__restrict__ tidx = idx2 + (roff >> 1);
-  // Every load below is unconditional with a clamped index (no branch => no wait at a branch
-  // merge), so the whole prologue is in flight at once: R*(W + W/2) operator loads, then the
-  // ghost ids, then the state gathers; the first wait is the one in front of the LDS writes.
-  T4 cf[R][W];
-  uint ix[R][W / 2];
-  constexpr int SU = 4;                                  // state slots per thread per pass
-  uint gi[SU];
-  auto loadGhostIds = [&](uint i0) {
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const uint i = i0 + t + TPB * u;
-      const uint g = (i >= n0 && i < mk) ? i - n0 : 0;   // ghost[] carries one pad element
-      gi[u] = PRO == 3 ? __builtin_nontemporal_load(&ghost[goff + g]) : ghost[goff + g];
-    }
-  };
-  // Issue order = completion order (one in-order counter per wave): the ghost ids go first, so
-  // the dependent state gathers can leave while the operator rows are still streaming in.
-  // PRO (FEM_TILE_PROLOGUE, same-box A/B on the 16M sphere): 0 ids after the operator 219.0;
-  // 1 ids first 220.2; 2 + operator rows as nontemporal loads 222.9; 3 + index streams
-  // nontemporal 224.6-228.7 G DOF-it/s (the read-once streams stop evicting the state, which
-  // is the only data with reuse between tiles and launches).
-  if (PRO >= 1) loadGhostIds(0);
-#pragma unroll
-  for (int q = 0; q < R; q++) {
-    const uint r = min(t + TPB * q, rpad - 1);         // rows in [rows, rpad) are zero padding
-#pragma unroll
-    for (int w = 0; w < W / 2; w++)                      // ids < 4096: both halves scale
-      ix[q][w] = (PRO == 3 ? __builtin_nontemporal_load(&tidx[w * rpad + r]) : tidx[w * rpad + r]) * (uint)sizeof(T2);
-  }
-#pragma unroll
-  for (int q = 0; q < R; q++) {
-    const uint r = min(t + TPB * q, rpad - 1);
-#pragma unroll
-    for (int w = 0; w < W; w++) cf[q][w] = PRO >= 2 ? ntload(&tcoef[w * rpad + r]) : tcoef[w * rpad + r];
-  }
-  if (X && xcnt) {                                       // tile-uniform
-    for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
-    for (uint i = t; i < xcnt; i += TPB) {
-      xs_coef[i] = tcoef[W * rpad + i];
-      xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
-    }
-  }
-  for (uint i0 = 0; i0 < mk; i0 += SU * TPB) {
-    T2 sv[SU];
-    if (PRO < 1 || i0 > 0) loadGhostIds(i0);
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const uint i = i0 + t + TPB * u;
-      sv[u] = src[i < n0 ? base + i : gi[u]];
-    }
-    if (IXL && i0 == 0) {
-#pragma unroll
-      for (int q = 0; q < R; q++)
-#pragma unroll
-        for (int w = 0; w < W / 2; w++) xs_ix[w * (TPB * R) + t + TPB * q] = ix[q][w];
-    }
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-      const uint i = i0 + t + TPB * u;
-      if (i < mk) cur[i] = sv[u];
-    }
-  }
-  __syncthreads();
-
-  for (int s = 0; s < nsteps; s++) {
-    const uint lim = mt[5 + k - 1 - s];
-#pragma unroll
-    for (int q = 0; q < R; q++) {
-      const uint r = t + TPB * q;
-      if (r < lim) {
-        const T2 self = cur[r];
-        T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
-        if constexpr (IXL) {
-#pragma unroll
-          for (int w = 0; w < W / 2; w++) ix[q][w] = xs_ix[w * (TPB * R) + r];
-        }
-#pragma unroll
-        for (int w = 0; w < W / 2; w++) asm volatile("" : "+v"(ix[q][w]));   // keep the unpacking in the loop, not in VGPRs
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-          const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);   // byte offset in the buffer
-          const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
-          const T4 c = cf[q][w];
-          const T dn = f.x - self.x, dc = f.y - self.y;
-          lapn += c.x * dn; lapc += c.x * dc;
-          gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
-          gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
-        }
-        if (X && xcnt) {                                 // entries W, W+1, ... of a wide row
-          const uint xi = xs_info[r];
-          for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {
-            const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
-            const T4 c = xs_coef[e];
-            const T dn = f.x - self.x, dc = f.y - self.y;
-            lapn += c.x * dn; lapc += c.x * dc;
-            gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
-            gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
-          }
-        }
-        nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
-      }
-      __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
-    }
-    __syncthreads();
-    T2 *tmp = cur; cur = nxt; nxt = tmp;
-  }
-  for (uint i = t; i < n0; i += TPB) dst[base + i] = cur[i];
-}
-
-
-// ---------------------------------------------------------------------------
-// Device assembly (initMeshStats on the GPU; reference src/mesh_function.cpp:70-397).
-//   assemble_rows_*_kernel : one thread per operator row, straight from the vertex positions:
-//     each entry names its neighbour and the two vertices opposite the edge (pack.cpp), so the
-//     thread rebuilds the (at most two) faces on the edge, and the faces left of the row's
-//     outgoing edges are all faces around the vertex once: lumped mass (sum of area/3), angle
-//     sum, cotangent sums (A3, :219-271), angle-weighted hat gradients and the longest edge (A4)
-//     are per-row sequential sums with the order fixed by the layout -- no atomics, no per-face
-//     intermediate in HBM, bit-reproducible.  Writes (w, Cx, Cy, Cz) straight into the plan's
-//     operator array.  Every face is recomputed by the rows that touch it (ALU is free here: the
-//     kernel moves 16 B table + 16 B result per entry and gathers positions from L2).
-//   assemble_faces_kernel : one thread per element, the reference's per-face/half-edge arrays
-//     (A1 angles + cotangents :70-160, A2 area :162-216, A4 longest edge :310-350, A5 gradVec12/13
-//     :351-397) as one 64-B record per face
-//     {ang_a, ang_b, ang_c, area | cot_a, cot_b, cot_c, maxEdge | g12.xyz, 0 | g13.xyz, 0};
-//     only run for fem_plan_face_records (checks, output), not needed by the operator.
-// ---------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T dev_acos(T x);
-template <> __device__ __forceinline__ float dev_acos<float>(float x) { return acosf(x); }
-template <> __device__ __forceinline__ double dev_acos<double>(double x) { return acos(x); }
-template <typename T> __device__ __forceinline__ T dev_tan(T x);
-template <> __device__ __forceinline__ float dev_tan<float>(float x) { return tanf(x); }
-template <> __device__ __forceinline__ double dev_tan<double>(double x) { return tan(x); }
-template <typename T> __device__ __forceinline__ T dev_sqrt(T x);
-template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return sqrtf(x); }
-template <> __device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
-template <typename T> __device__ __forceinline__ T dev_rsqrt(T x);
-template <> __device__ __forceinline__ float dev_rsqrt<float>(float x) { return __frsqrt_rn(x); }   // v_rsq_f32, 1 ulp
-template <> __device__ __forceinline__ double dev_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
-
-template <typename T>
-__device__ __forceinline__ void corner_angle(const T *p1, const T *p2, const T *p3, T &ang, T &cot) {
-  // angle at p2 between p1 and p3; precedence of mesh_function.cpp:126: dot(v21, v23 / (|v21| |v23|))
-  T v21[3], v23[3], n21 = 0, n23 = 0, d = 0;
-#pragma unroll
-  for (int k = 0; k < 3; k++) { v21[k] = p1[k] - p2[k]; v23[k] = p3[k] - p2[k]; n21 += v21[k] * v21[k]; n23 += v23[k] * v23[k]; }
-  const T sden = dev_sqrt(n21) * dev_sqrt(n23);
-#pragma unroll
-  for (int k = 0; k < 3; k++) d += v21[k] * (v23[k] / sden);
-  ang = dev_acos(d);
-  cot = (T)1 / dev_tan(ang);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void assemble_faces_kernel(const typename Vec<T>::t4 *__restrict__ pos,
-                                                             const uint *__restrict__ tri0, const uint *__restrict__ tri1,
-                                                             const uint *__restrict__ tri2, typename Vec<T>::t4 *__restrict__ rec,
-                                                             uint F, double *__restrict__ blockMax) {
-  typedef typename Vec<T>::t4 T4;
-  const uint f = blockIdx.x * blockDim.x + threadIdx.x;
-  T me = 0;
-  if (f < F) {
-    const T4 A = pos[tri0[f]], B = pos[tri1[f]], C = pos[tri2[f]];
-    const T a[3] = {A.x, A.y, A.z}, b[3] = {B.x, B.y, B.z}, c[3] = {C.x, C.y, C.z};
-    T4 r0, r1, r2, r3;
-    corner_angle<T>(c, a, b, r0.x, r1.x);               // half-edge c->a ends at a
-    corner_angle<T>(a, b, c, r0.y, r1.y);
-    corner_angle<T>(b, c, a, r0.z, r1.z);
-    // area = |(p1-p2) x (p3-p2)| / 2 with (p1,p2,p3) = (c,a,b)
-    T u[3], v[3], e1[3], e2[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { u[k] = c[k] - a[k]; v[k] = b[k] - a[k]; e1[k] = c[k] - b[k]; e2[k] = a[k] - b[k]; }
-    const T cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
-    const T area = dev_sqrt(cx * cx + cy * cy + cz * cz) / 2;
-    r0.w = area;
-    T nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
-    const T nl = dev_sqrt(nx * nx + ny * ny + nz * nz);
-    if (nl != 0) { nx /= nl; ny /= nl; nz /= nl; } else { nx = ny = nz = 0; }
-    const T twoA = 2 * area;
-    // gradVec12 = N x (pt1 - pt3) / 2A, (pt1, pt3) = (c, b);  gradVec13 = N x (pt2 - pt1) / 2A = N x (a - c) / 2A
-    r2.x = (ny * e1[2] - nz * e1[1]) / twoA; r2.y = (nz * e1[0] - nx * e1[2]) / twoA; r2.z = (nx * e1[1] - ny * e1[0]) / twoA; r2.w = 0;
-    r3.x = (ny * (-u[2]) - nz * (-u[1])) / twoA; r3.y = (nz * (-u[0]) - nx * (-u[2])) / twoA; r3.z = (nx * (-u[1]) - ny * (-u[0])) / twoA; r3.w = 0;
-    const T lab = dev_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    const T lbc = dev_sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
-    const T lca = dev_sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    me = fmax(lab, fmax(lbc, lca));
-    r1.w = me;
-    rec[4 * (size_t)f] = r0; rec[4 * (size_t)f + 1] = r1; rec[4 * (size_t)f + 2] = r2; rec[4 * (size_t)f + 3] = r3;
-  }
-  // A4: longest edge -> wave shuffle reduction, one partial per workgroup (a single-address atomic
-  // per wave would serialise ~F/64 atomics at the memory side); max_reduce_kernel finishes it
-  __shared__ double s_part[4];
-  double m = (double)me;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
-}
-
-__global__ __launch_bounds__(1024) void max_reduce_kernel(const double *__restrict__ part, uint n, double *__restrict__ out) {
-  __shared__ double s_part[16];
-  double m = 0;
-  for (uint i = threadIdx.x; i < n; i += 1024) m = fmax(m, part[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; i++) m = fmax(m, s_part[i]);
-    *out = m;
-  }
-}
-
-constexpr int kTileWDev = 6;       // entries per row of the tile layout (= kTileW)
-
-// One corner of the fan around v: face (v, p, q), counter-clockwise, e1 = p - v, e2 = q - v.
-//   c = e1 x e2 (|c| = 2 area), angle at v = acos(e1.e2 / (|e1||e2|)),
-//   cot at q = (|e2|^2 - e1.e2) / |c|, cot at p = (|e1|^2 - e1.e2) / |c|,
-//   grad phi_p = e2 x c / |c|^2, grad phi_q = c x e1 / |c|^2
-// (hat gradient = normal x opposite edge / 2 area).  Same quantities as mesh_function.cpp:70-397
-// (A1 angles/cotangents, A2 areas, A5 gradVec12/13), per row instead of per face.
-template <typename T> struct FanFace { T cx, cy, cz, c2, d, l1, l2; };
-template <typename T>
-__device__ __forceinline__ FanFace<T> fan_face(const T *e1, const T *e2) {
-  FanFace<T> f;
-  f.cx = e1[1] * e2[2] - e1[2] * e2[1]; f.cy = e1[2] * e2[0] - e1[0] * e2[2]; f.cz = e1[0] * e2[1] - e1[1] * e2[0];
-  f.c2 = f.cx * f.cx + f.cy * f.cy + f.cz * f.cz;
-  f.d = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
-  f.l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
-  f.l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
-  return f;
-}
-
-// One operator row straight from the positions: entries e(k) = first + k * stride for k < SPLIT,
-// xfirst + (k - SPLIT) beyond (the tile layout's extras of a wide row), k < width <= W.
-// Per entry (v -> j): face (v, j, o1) on the left and (v, o2, j) on the right give the cotangents
-// opposite the edge (A3, mesh_function.cpp:219-271) and the angle-weighted hat gradients of j
-// (mesh_function.h:35-110); the faces left of v's outgoing half-edges are all faces around v once,
-// so the lumped mass and the angle sum are row sums of the same quantities.  Returns the longest
-// edge at v (A4, :310-350).
-template <typename T>
-__device__ __forceinline__ typename Vec<T>::t4 entry_terms(const typename Vec<T>::t4 *__restrict__ pos,
-                                                           const typename Vec<T>::t4 &P, uint vg, const uint4 &t, T &area3,
-                                                           T &theta, T &maxe2) {
-  typedef typename Vec<T>::t4 T4;
-  const bool real = t.w != 0u, has1 = real && t.y != ~0u, has2 = real && t.z != ~0u;
-  const T4 J = pos[real ? t.x : vg], O1 = pos[has1 ? t.y : vg], O2 = pos[has2 ? t.z : vg];
-  const T ej[3] = {J.x - P.x, J.y - P.y, J.z - P.z};
-  const T e1[3] = {O1.x - P.x, O1.y - P.y, O1.z - P.z};
-  const T e2[3] = {O2.x - P.x, O2.y - P.y, O2.z - P.z};
-  T4 a;
-  a.x = a.y = a.z = a.w = 0;
-  if (has1) {                                          // face (v, j, o1): p = j, q = o1
-    const FanFace<T> f = fan_face<T>(ej, e1);
-    const T rcn = dev_rsqrt(f.c2);                     // 1 / |c|
-    const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
-    a.x += (f.l2 - f.d) * rcn;                         // cot at o1
-    const T s = ang * rcn * rcn;                       // angle * grad phi_j, grad phi_p = e2 x c / |c|^2
-    a.y += s * (e1[1] * f.cz - e1[2] * f.cy); a.z += s * (e1[2] * f.cx - e1[0] * f.cz); a.w += s * (e1[0] * f.cy - e1[1] * f.cx);
-    theta += ang; area3 += f.c2 * rcn / 6;             // area / 3 = |c| / 6
-  }
-  if (has2) {                                          // face (v, o2, j): p = o2, q = j
-    const FanFace<T> f = fan_face<T>(e2, ej);
-    const T rcn = dev_rsqrt(f.c2);
-    const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
-    a.x += (f.l1 - f.d) * rcn;                         // cot at o2
-    const T s = ang * rcn * rcn;                       // grad phi_q = c x e1 / |c|^2
-    a.y += s * (f.cy * e2[2] - f.cz * e2[1]); a.z += s * (f.cz * e2[0] - f.cx * e2[2]); a.w += s * (f.cx * e2[1] - f.cy * e2[0]);
-  }
-  if (real) maxe2 = fmax(maxe2, ej[0] * ej[0] + ej[1] * ej[1] + ej[2] * ej[2]);
-  return a;
-}
-
-template <typename T>
-__device__ __forceinline__ typename Vec<T>::t4 entry_scale(const typename Vec<T>::t4 &a, T area3, T theta) {
-  typename Vec<T>::t4 o;
-  o.x = area3 > 0 ? a.x / (2 * area3) : (T)0;
-  if (theta > 0) { o.y = a.y / theta; o.z = a.z / theta; o.w = a.w / theta; } else { o.y = o.z = o.w = 0; }
-  return o;
-}
-
-// W <= 12: fully unrolled, unnormalised terms in registers.  W = 0: any width, a plain loop that
-// parks the unnormalised terms in the output array and rescales them in a second sweep.
-template <typename T, int W, int SPLIT = W>
-__device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
-                                          typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
-                                          uint width, size_t xfirst = 0) {
-  typedef typename Vec<T>::t4 T4;
-  auto at = [&](int k) { return k < SPLIT ? first + k * stride : xfirst + (size_t)(k - SPLIT); };
-  const T4 P = pos[vg];
-  T area3 = 0, theta = 0, maxe2 = 0;
-  if constexpr (W > 0) {
-    uint4 t[W];
-#pragma unroll
-    for (int k = 0; k < W; k++) t[k] = (uint)k < width ? topo[at(k)] : make_uint4(0u, ~0u, ~0u, 0u);
-    T4 acc[W];
-#pragma unroll
-    for (int k = 0; k < W; k++) acc[k] = entry_terms<T>(pos, P, vg, t[k], area3, theta, maxe2);
-#pragma unroll
-    for (int k = 0; k < W; k++)
-      if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], area3, theta);
-  } else {
-    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_terms<T>(pos, P, vg, topo[at(k)], area3, theta, maxe2);
-    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_scale<T>(coef[at(k)], area3, theta);
-  }
-  return dev_sqrt(maxe2);
-}
-
-template <typename T>
-__device__ __forceinline__ T assemble_row_wide(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
-                                               typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
-                                               uint width, size_t xfirst) {
-  return assemble_row<T, 0, kTileWDev>(pos, topo, coef, vg, first, stride, width, xfirst);
-}
-
-// longest edge: wave shuffle reduction, one partial per workgroup (max_reduce_kernel finishes it)
-__device__ __forceinline__ void block_max_256(double m, double *__restrict__ blockMax) {
-  __shared__ double s_part[4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
-                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ slice_off,
-                                                                 const uint *__restrict__ rowg,
-                                                                 typename Vec<T>::t4 *__restrict__ coef, uint nslices, uint V,
-                                                                 double *__restrict__ blockMax) {
-  const uint slice = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-  T me = 0;
-  if (slice < nslices) {
-    const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
-    const uint row = min(slice * 64 + lane, V - 1);    // rows >= V: padding entries only (flag 0)
-    const uint vg = rowg[row];
-    if (width <= 6) me = assemble_row<T, 6>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
-    else if (width <= 12) me = assemble_row<T, 12>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
-    else me = assemble_row<T, 0, (1 << 30)>(pos, topo, coef, vg, (size_t)off + lane, 64, width);   // no split: all entries strided
-  }
-  block_max_256((double)me, blockMax);
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ pos,
-                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ meta,
-                                                                 const uint *__restrict__ ghost, const uint *__restrict__ xinfo,
-                                                                 const uint *__restrict__ rowg,
-                                                                 typename Vec<T>::t4 *__restrict__ coef, uint W,
-                                                                 double *__restrict__ blockMax) {
-  const uint *mt = meta + 16 * (size_t)blockIdx.x;
-  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], n0 = mt[5], rows = mt[5 + mt[4] - 1];
-  const uint xoff = mt[14], xcnt = mt[15];
-  T me = 0;
-  for (uint r = threadIdx.x; r < rows; r += blockDim.x) {
-    const uint vg = rowg[r < n0 ? base + r : ghost[goff + (r - n0)]];
-    const uint xi = xcnt ? xinfo[xoff + r] : 0u, nx = xi >> 16;
-    const size_t first = (size_t)roff + r, xfirst = (size_t)roff + (size_t)W * rpad + (xi & 0xffffu);
-    T e;
-    if (nx == 0) e = assemble_row<T, kTileWDev>(pos, topo, coef, vg, first, rpad, W);
-    else if (nx <= 6) e = assemble_row<T, 12, kTileWDev>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
-    else e = assemble_row_wide<T>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
-    me = fmax(me, e);
-  }
-  block_max_256((double)me, blockMax);
-}
-
-// seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
-template <typename T>
-__global__ __launch_bounds__(256) void deform_kernel(const typename Vec<T>::t4 *__restrict__ base,
-                                                     typename Vec<T>::t4 *__restrict__ pos, uint V, T amp, T q, T phase) {
-  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V) return;
-  typename Vec<T>::t4 p = base[i];
-  const T s = (T)1 + amp * sin(q * p.x + phase) * cos(q * p.y - (T)0.5 * phase) * sin(q * p.z + (T)0.25 * phase);
-  p.x *= s; p.y *= s; p.z *= s;
-  pos[i] = p;
-}
-
-
-// ---------------------------------------------------------------------------
-// Result output (formatKernel + the two thrust reductions of format(), reference
-// src/FEM_common.cu:183-230, without GL): min/max of n over the vertices, then
-// RGBA = (n^, 1 - n^, 1 - n^, 1) with n^ = (n - min) / (max - min).
-// ---------------------------------------------------------------------------
-template <typename T2>
-__global__ __launch_bounds__(256) void minmax_kernel(const T2 *__restrict__ state, uint V, double *__restrict__ part) {
-  __shared__ double s_lo[4], s_hi[4];
-  double lo = 1e300, hi = -1e300;
-  for (uint i = blockIdx.x * blockDim.x + threadIdx.x; i < V; i += gridDim.x * blockDim.x) {
-    const double x = (double)state[i].x;
-    lo = fmin(lo, x); hi = fmax(hi, x);
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
-  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
-    part[2 * blockIdx.x + 1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
-  }
-}
-
-__global__ __launch_bounds__(256) void minmax_final_kernel(const double *__restrict__ part, uint n, double *__restrict__ out) {
-  __shared__ double s_lo[4], s_hi[4];
-  double lo = 1e300, hi = -1e300;
-  for (uint i = threadIdx.x; i < n; i += 256) { lo = fmin(lo, part[2 * i]); hi = fmax(hi, part[2 * i + 1]); }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { lo = fmin(lo, __shfl_xor(lo, o)); hi = fmax(hi, __shfl_xor(hi, o)); }
-  if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6] = lo; s_hi[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    out[0] = fmin(fmin(s_lo[0], s_lo[1]), fmin(s_lo[2], s_lo[3]));
-    out[1] = fmax(fmax(s_hi[0], s_hi[1]), fmax(s_hi[2], s_hi[3]));
-  }
-}
-
-template <typename T2>
-__global__ __launch_bounds__(256) void format_kernel(const T2 *__restrict__ state, uint V, const double *__restrict__ mm,
-                                                     double4 *__restrict__ rgba) {
-  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= V) return;
-  const double n = ((double)state[i].x - mm[0]) / (mm[1] - mm[0]);
-  rgba[i] = make_double4(n, 1 - n, 1 - n, 1.0);
-}
-
-// halo pack: dst[i] = state[send_idx[i]] (8 or 16 B per lane, coalesced stores)
-template <typename T2>
-__global__ __launch_bounds__(256) void pack_halo_kernel(const T2 *__restrict__ state, const uint *__restrict__ send_idx,
-                                                        T2 *__restrict__ dst, uint n) {
-  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = state[send_idx[i]];
-}
+#include "kernels_common.hpp"
+#include "kernels_step.hpp"
+#include "kernels_assembly.hpp"
+#include "kernels_output.hpp"
 
 template <typename T> struct DevBuf {
   T *p = nullptr;

@@ -1,0 +1,277 @@
+// kernels_assembly.hpp -- operator assembly on the device (initMeshStats on the GPU), per-face records, deformation
+// Included by device.hip inside its anonymous namespace (one translation unit: the kernels are
+// launched from the C-ABI functions there).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// Device assembly (initMeshStats on the GPU; reference src/mesh_function.cpp:70-397).
+//   assemble_rows_*_kernel : one thread per operator row, straight from the vertex positions:
+//     each entry names its neighbour and the two vertices opposite the edge (pack.cpp), so the
+//     thread rebuilds the (at most two) faces on the edge, and the faces left of the row's
+//     outgoing edges are all faces around the vertex once: lumped mass (sum of area/3), angle
+//     sum, cotangent sums (A3, :219-271), angle-weighted hat gradients and the longest edge (A4)
+//     are per-row sequential sums with the order fixed by the layout -- no atomics, no per-face
+//     intermediate in HBM, bit-reproducible.  Writes (w, Cx, Cy, Cz) straight into the plan's
+//     operator array.  Every face is recomputed by the rows that touch it (ALU is free here: the
+//     kernel moves 16 B table + 16 B result per entry and gathers positions from L2).
+//   assemble_faces_kernel : one thread per element, the reference's per-face/half-edge arrays
+//     (A1 angles + cotangents :70-160, A2 area :162-216, A4 longest edge :310-350, A5 gradVec12/13
+//     :351-397) as one 64-B record per face
+//     {ang_a, ang_b, ang_c, area | cot_a, cot_b, cot_c, maxEdge | g12.xyz, 0 | g13.xyz, 0};
+//     only run for fem_plan_face_records (checks, output), not needed by the operator.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T dev_acos(T x);
+template <> __device__ __forceinline__ float dev_acos<float>(float x) { return acosf(x); }
+template <> __device__ __forceinline__ double dev_acos<double>(double x) { return acos(x); }
+template <typename T> __device__ __forceinline__ T dev_tan(T x);
+template <> __device__ __forceinline__ float dev_tan<float>(float x) { return tanf(x); }
+template <> __device__ __forceinline__ double dev_tan<double>(double x) { return tan(x); }
+template <typename T> __device__ __forceinline__ T dev_sqrt(T x);
+template <> __device__ __forceinline__ float dev_sqrt<float>(float x) { return sqrtf(x); }
+template <> __device__ __forceinline__ double dev_sqrt<double>(double x) { return sqrt(x); }
+template <typename T> __device__ __forceinline__ T dev_rsqrt(T x);
+template <> __device__ __forceinline__ float dev_rsqrt<float>(float x) { return __frsqrt_rn(x); }   // v_rsq_f32, 1 ulp
+template <> __device__ __forceinline__ double dev_rsqrt<double>(double x) { return 1.0 / sqrt(x); }
+
+template <typename T>
+__device__ __forceinline__ void corner_angle(const T *p1, const T *p2, const T *p3, T &ang, T &cot) {
+  // angle at p2 between p1 and p3; precedence of mesh_function.cpp:126: dot(v21, v23 / (|v21| |v23|))
+  T v21[3], v23[3], n21 = 0, n23 = 0, d = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { v21[k] = p1[k] - p2[k]; v23[k] = p3[k] - p2[k]; n21 += v21[k] * v21[k]; n23 += v23[k] * v23[k]; }
+  const T sden = dev_sqrt(n21) * dev_sqrt(n23);
+#pragma unroll
+  for (int k = 0; k < 3; k++) d += v21[k] * (v23[k] / sden);
+  ang = dev_acos(d);
+  cot = (T)1 / dev_tan(ang);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_faces_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                             const uint *__restrict__ tri0, const uint *__restrict__ tri1,
+                                                             const uint *__restrict__ tri2, typename Vec<T>::t4 *__restrict__ rec,
+                                                             uint F, double *__restrict__ blockMax) {
+  typedef typename Vec<T>::t4 T4;
+  const uint f = blockIdx.x * blockDim.x + threadIdx.x;
+  T me = 0;
+  if (f < F) {
+    const T4 A = pos[tri0[f]], B = pos[tri1[f]], C = pos[tri2[f]];
+    const T a[3] = {A.x, A.y, A.z}, b[3] = {B.x, B.y, B.z}, c[3] = {C.x, C.y, C.z};
+    T4 r0, r1, r2, r3;
+    corner_angle<T>(c, a, b, r0.x, r1.x);               // half-edge c->a ends at a
+    corner_angle<T>(a, b, c, r0.y, r1.y);
+    corner_angle<T>(b, c, a, r0.z, r1.z);
+    // area = |(p1-p2) x (p3-p2)| / 2 with (p1,p2,p3) = (c,a,b)
+    T u[3], v[3], e1[3], e2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { u[k] = c[k] - a[k]; v[k] = b[k] - a[k]; e1[k] = c[k] - b[k]; e2[k] = a[k] - b[k]; }
+    const T cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+    const T area = dev_sqrt(cx * cx + cy * cy + cz * cz) / 2;
+    r0.w = area;
+    T nx = e1[1] * e2[2] - e1[2] * e2[1], ny = e1[2] * e2[0] - e1[0] * e2[2], nz = e1[0] * e2[1] - e1[1] * e2[0];
+    const T nl = dev_sqrt(nx * nx + ny * ny + nz * nz);
+    if (nl != 0) { nx /= nl; ny /= nl; nz /= nl; } else { nx = ny = nz = 0; }
+    const T twoA = 2 * area;
+    // gradVec12 = N x (pt1 - pt3) / 2A, (pt1, pt3) = (c, b);  gradVec13 = N x (pt2 - pt1) / 2A = N x (a - c) / 2A
+    r2.x = (ny * e1[2] - nz * e1[1]) / twoA; r2.y = (nz * e1[0] - nx * e1[2]) / twoA; r2.z = (nx * e1[1] - ny * e1[0]) / twoA; r2.w = 0;
+    r3.x = (ny * (-u[2]) - nz * (-u[1])) / twoA; r3.y = (nz * (-u[0]) - nx * (-u[2])) / twoA; r3.z = (nx * (-u[1]) - ny * (-u[0])) / twoA; r3.w = 0;
+    const T lab = dev_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const T lbc = dev_sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    const T lca = dev_sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    me = fmax(lab, fmax(lbc, lca));
+    r1.w = me;
+    rec[4 * (size_t)f] = r0; rec[4 * (size_t)f + 1] = r1; rec[4 * (size_t)f + 2] = r2; rec[4 * (size_t)f + 3] = r3;
+  }
+  // A4: longest edge -> wave shuffle reduction, one partial per workgroup (a single-address atomic
+  // per wave would serialise ~F/64 atomics at the memory side); max_reduce_kernel finishes it
+  __shared__ double s_part[4];
+  double m = (double)me;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
+}
+
+__global__ __launch_bounds__(1024) void max_reduce_kernel(const double *__restrict__ part, uint n, double *__restrict__ out) {
+  __shared__ double s_part[16];
+  double m = 0;
+  for (uint i = threadIdx.x; i < n; i += 1024) m = fmax(m, part[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; i++) m = fmax(m, s_part[i]);
+    *out = m;
+  }
+}
+
+constexpr int kTileWDev = 6;       // entries per row of the tile layout (= kTileW)
+
+// One corner of the fan around v: face (v, p, q), counter-clockwise, e1 = p - v, e2 = q - v.
+//   c = e1 x e2 (|c| = 2 area), angle at v = acos(e1.e2 / (|e1||e2|)),
+//   cot at q = (|e2|^2 - e1.e2) / |c|, cot at p = (|e1|^2 - e1.e2) / |c|,
+//   grad phi_p = e2 x c / |c|^2, grad phi_q = c x e1 / |c|^2
+// (hat gradient = normal x opposite edge / 2 area).  Same quantities as mesh_function.cpp:70-397
+// (A1 angles/cotangents, A2 areas, A5 gradVec12/13), per row instead of per face.
+template <typename T> struct FanFace { T cx, cy, cz, c2, d, l1, l2; };
+template <typename T>
+__device__ __forceinline__ FanFace<T> fan_face(const T *e1, const T *e2) {
+  FanFace<T> f;
+  f.cx = e1[1] * e2[2] - e1[2] * e2[1]; f.cy = e1[2] * e2[0] - e1[0] * e2[2]; f.cz = e1[0] * e2[1] - e1[1] * e2[0];
+  f.c2 = f.cx * f.cx + f.cy * f.cy + f.cz * f.cz;
+  f.d = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+  f.l1 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+  f.l2 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+  return f;
+}
+
+// One operator row straight from the positions: entries e(k) = first + k * stride for k < SPLIT,
+// xfirst + (k - SPLIT) beyond (the tile layout's extras of a wide row), k < width <= W.
+// Per entry (v -> j): face (v, j, o1) on the left and (v, o2, j) on the right give the cotangents
+// opposite the edge (A3, mesh_function.cpp:219-271) and the angle-weighted hat gradients of j
+// (mesh_function.h:35-110); the faces left of v's outgoing half-edges are all faces around v once,
+// so the lumped mass and the angle sum are row sums of the same quantities.  Returns the longest
+// edge at v (A4, :310-350).
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t4 entry_terms(const typename Vec<T>::t4 *__restrict__ pos,
+                                                           const typename Vec<T>::t4 &P, uint vg, const uint4 &t, T &area3,
+                                                           T &theta, T &maxe2) {
+  typedef typename Vec<T>::t4 T4;
+  const bool real = t.w != 0u, has1 = real && t.y != ~0u, has2 = real && t.z != ~0u;
+  const T4 J = pos[real ? t.x : vg], O1 = pos[has1 ? t.y : vg], O2 = pos[has2 ? t.z : vg];
+  const T ej[3] = {J.x - P.x, J.y - P.y, J.z - P.z};
+  const T e1[3] = {O1.x - P.x, O1.y - P.y, O1.z - P.z};
+  const T e2[3] = {O2.x - P.x, O2.y - P.y, O2.z - P.z};
+  T4 a;
+  a.x = a.y = a.z = a.w = 0;
+  if (has1) {                                          // face (v, j, o1): p = j, q = o1
+    const FanFace<T> f = fan_face<T>(ej, e1);
+    const T rcn = dev_rsqrt(f.c2);                     // 1 / |c|
+    const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
+    a.x += (f.l2 - f.d) * rcn;                         // cot at o1
+    const T s = ang * rcn * rcn;                       // angle * grad phi_j, grad phi_p = e2 x c / |c|^2
+    a.y += s * (e1[1] * f.cz - e1[2] * f.cy); a.z += s * (e1[2] * f.cx - e1[0] * f.cz); a.w += s * (e1[0] * f.cy - e1[1] * f.cx);
+    theta += ang; area3 += f.c2 * rcn / 6;             // area / 3 = |c| / 6
+  }
+  if (has2) {                                          // face (v, o2, j): p = o2, q = j
+    const FanFace<T> f = fan_face<T>(e2, ej);
+    const T rcn = dev_rsqrt(f.c2);
+    const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
+    a.x += (f.l1 - f.d) * rcn;                         // cot at o2
+    const T s = ang * rcn * rcn;                       // grad phi_q = c x e1 / |c|^2
+    a.y += s * (f.cy * e2[2] - f.cz * e2[1]); a.z += s * (f.cz * e2[0] - f.cx * e2[2]); a.w += s * (f.cx * e2[1] - f.cy * e2[0]);
+  }
+  if (real) maxe2 = fmax(maxe2, ej[0] * ej[0] + ej[1] * ej[1] + ej[2] * ej[2]);
+  return a;
+}
+
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t4 entry_scale(const typename Vec<T>::t4 &a, T area3, T theta) {
+  typename Vec<T>::t4 o;
+  o.x = area3 > 0 ? a.x / (2 * area3) : (T)0;
+  if (theta > 0) { o.y = a.y / theta; o.z = a.z / theta; o.w = a.w / theta; } else { o.y = o.z = o.w = 0; }
+  return o;
+}
+
+// W <= 12: fully unrolled, unnormalised terms in registers.  W = 0: any width, a plain loop that
+// parks the unnormalised terms in the output array and rescales them in a second sweep.
+template <typename T, int W, int SPLIT = W>
+__device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
+                                          typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
+                                          uint width, size_t xfirst = 0) {
+  typedef typename Vec<T>::t4 T4;
+  auto at = [&](int k) { return k < SPLIT ? first + k * stride : xfirst + (size_t)(k - SPLIT); };
+  const T4 P = pos[vg];
+  T area3 = 0, theta = 0, maxe2 = 0;
+  if constexpr (W > 0) {
+    uint4 t[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) t[k] = (uint)k < width ? topo[at(k)] : make_uint4(0u, ~0u, ~0u, 0u);
+    T4 acc[W];
+#pragma unroll
+    for (int k = 0; k < W; k++) acc[k] = entry_terms<T>(pos, P, vg, t[k], area3, theta, maxe2);
+#pragma unroll
+    for (int k = 0; k < W; k++)
+      if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], area3, theta);
+  } else {
+    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_terms<T>(pos, P, vg, topo[at(k)], area3, theta, maxe2);
+    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_scale<T>(coef[at(k)], area3, theta);
+  }
+  return dev_sqrt(maxe2);
+}
+
+template <typename T>
+__device__ __forceinline__ T assemble_row_wide(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
+                                               typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
+                                               uint width, size_t xfirst) {
+  return assemble_row<T, 0, kTileWDev>(pos, topo, coef, vg, first, stride, width, xfirst);
+}
+
+// longest edge: wave shuffle reduction, one partial per workgroup (max_reduce_kernel finishes it)
+__device__ __forceinline__ void block_max_256(double m, double *__restrict__ blockMax) {
+  __shared__ double s_part[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ slice_off,
+                                                                 const uint *__restrict__ rowg,
+                                                                 typename Vec<T>::t4 *__restrict__ coef, uint nslices, uint V,
+                                                                 double *__restrict__ blockMax) {
+  const uint slice = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  T me = 0;
+  if (slice < nslices) {
+    const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
+    const uint row = min(slice * 64 + lane, V - 1);    // rows >= V: padding entries only (flag 0)
+    const uint vg = rowg[row];
+    if (width <= 6) me = assemble_row<T, 6>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
+    else if (width <= 12) me = assemble_row<T, 12>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
+    else me = assemble_row<T, 0, (1 << 30)>(pos, topo, coef, vg, (size_t)off + lane, 64, width);   // no split: all entries strided
+  }
+  block_max_256((double)me, blockMax);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ meta,
+                                                                 const uint *__restrict__ ghost, const uint *__restrict__ xinfo,
+                                                                 const uint *__restrict__ rowg,
+                                                                 typename Vec<T>::t4 *__restrict__ coef, uint W,
+                                                                 double *__restrict__ blockMax) {
+  const uint *mt = meta + 16 * (size_t)blockIdx.x;
+  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], n0 = mt[5], rows = mt[5 + mt[4] - 1];
+  const uint xoff = mt[14], xcnt = mt[15];
+  T me = 0;
+  for (uint r = threadIdx.x; r < rows; r += blockDim.x) {
+    const uint vg = rowg[r < n0 ? base + r : ghost[goff + (r - n0)]];
+    const uint xi = xcnt ? xinfo[xoff + r] : 0u, nx = xi >> 16;
+    const size_t first = (size_t)roff + r, xfirst = (size_t)roff + (size_t)W * rpad + (xi & 0xffffu);
+    T e;
+    if (nx == 0) e = assemble_row<T, kTileWDev>(pos, topo, coef, vg, first, rpad, W);
+    else if (nx <= 6) e = assemble_row<T, 12, kTileWDev>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+    else e = assemble_row_wide<T>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+    me = fmax(me, e);
+  }
+  block_max_256((double)me, blockMax);
+}
+
+// seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
+template <typename T>
+__global__ __launch_bounds__(256) void deform_kernel(const typename Vec<T>::t4 *__restrict__ base,
+                                                     typename Vec<T>::t4 *__restrict__ pos, uint V, T amp, T q, T phase) {
+  const uint i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V) return;
+  typename Vec<T>::t4 p = base[i];
+  const T s = (T)1 + amp * sin(q * p.x + phase) * cos(q * p.y - (T)0.5 * phase) * sin(q * p.z + (T)0.25 * phase);
+  p.x *= s; p.y *= s; p.z *= s;
+  pos[i] = p;
+}
+
+

@@ -1,0 +1,285 @@
+// kernels_step.hpp -- the time-step kernels: ref_step_kernel (reference layout, what `step` launches), sell_step_kernel (sliced ELL), tile_step_kernel (fused k steps)
+// Included by device.hip inside its anonymous namespace (one translation unit: the kernels are
+// launched from the C-ABI functions there).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// Reference-layout step (FEM_common.cu:82-166).  Differences from the reference
+// kernel, none of them in the arithmetic: all loops are block-strided, so no
+// thread leaves before a barrier and a partition may hold more faces or
+// vertices than the block has threads (the reference returns early at :99-100
+// and :138-139); the double accumulator uses the LDS f64 add instead of a CAS
+// loop (:15-31).
+// LDS: wg[size] double, then nvGrads[3*size], cvGrads[3*size] float = 32 B/vertex.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ref_step_kernel(
+    const double2 *__restrict__ fn_src, double2 *__restrict__ fn_dst, const uint *__restrict__ fv,
+    const double *__restrict__ fv_weights, uint fv_pitch, uint fvw_pitch, const uint *__restrict__ nbr,
+    const double *__restrict__ vtxW, uint vw_pitch, const double *__restrict__ vertex_weights,
+    uint vv_pitch, uint vws_pitch, uint vv_size, const float4 *__restrict__ grads, uint he_pitch,
+    const uint *__restrict__ vertex_parts, const uint *__restrict__ block_face_count, double dt,
+    ModelD m) {
+  extern __shared__ double s_mem[];
+  const uint p = blockIdx.x;
+  const uint base = vertex_parts[p];
+  const uint size = vertex_parts[p + 1] - base;
+  double *s_wg = s_mem;
+  float *s_nv = reinterpret_cast<float *>(s_wg + size);
+  float *s_cv = s_nv + 3 * size;
+
+  for (uint i = threadIdx.x; i < size; i += blockDim.x) {
+    s_wg[i] = 0.0;
+    s_nv[3 * i] = s_nv[3 * i + 1] = s_nv[3 * i + 2] = 0.0f;
+    s_cv[3 * i] = s_cv[3 * i + 1] = s_cv[3 * i + 2] = 0.0f;
+  }
+  __syncthreads();
+
+  /* face gradients, scattered to the owned corners */
+  const uint nfaces = block_face_count[p];
+  const size_t fvb = (size_t)p * 3 * fv_pitch, fwb = (size_t)p * 3 * fvw_pitch, heb = (size_t)p * 2 * he_pitch;
+  for (uint t = threadIdx.x; t < nfaces; t += blockDim.x) {
+    const uint i0 = fv[fvb + t], i1 = fv[fvb + fv_pitch + t], i2 = fv[fvb + 2 * (size_t)fv_pitch + t];
+    const double2 v1 = fn_src[i2], a = fn_src[i0], b = fn_src[i1];
+    const float d12x = (float)(a.x - v1.x), d12y = (float)(a.y - v1.y);
+    const float d13x = (float)(b.x - v1.x), d13y = (float)(b.y - v1.y);
+    const float4 g12 = grads[heb + t], g13 = grads[heb + he_pitch + t];
+    const float nvx = g12.x * d12x + g13.x * d13x, nvy = g12.y * d12x + g13.y * d13x, nvz = g12.z * d12x + g13.z * d13x;
+    const float cvx = g12.x * d12y + g13.x * d13y, cvy = g12.y * d12y + g13.y * d13y, cvz = g12.z * d12y + g13.z * d13y;
+    const uint idx[3] = {i0, i1, i2};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint li = idx[j] - base;              // unsigned wrap makes "below base" large
+      if (li < size) {
+        const double weight = fv_weights[fwb + (size_t)j * fvw_pitch + t];
+        atomicAdd(&s_nv[3 * li], (float)(nvx * weight));
+        atomicAdd(&s_nv[3 * li + 1], (float)(nvy * weight));
+        atomicAdd(&s_nv[3 * li + 2], (float)(nvz * weight));
+        atomicAdd(&s_cv[3 * li], (float)(cvx * weight));
+        atomicAdd(&s_cv[3 * li + 1], (float)(cvy * weight));
+        atomicAdd(&s_cv[3 * li + 2], (float)(cvz * weight));
+        unsafeAtomicAdd(&s_wg[li], weight);
+      }
+    }
+  }
+  __syncthreads();
+
+  /* laplacian, vertex gradients, update */
+  const size_t nb = (size_t)p * (vv_size + 1) * vv_pitch, wb = (size_t)p * vv_size * vws_pitch;
+  for (uint t = threadIdx.x; t < size; t += blockDim.x) {
+    const uint i = base + t;
+    const double2 s = fn_src[i];
+    const double vW = vtxW[(size_t)p * vw_pitch + t];
+    double lx = s.x * vW, ly = s.y * vW;
+    const uint end = nbr[nb + t];
+    for (uint j = 0; j < end; j++) {
+      const uint nIdx = nbr[nb + (size_t)vv_pitch * (j + 1) + t];
+      const double hW = vertex_weights[wb + (size_t)vws_pitch * j + t];
+      const double2 f = fn_src[nIdx];
+      lx += f.x * hW; ly += f.y * hW;
+    }
+    double dotP = 0;
+    const double wg = s_wg[t];
+    if (wg > 0) {
+      const float w = (float)wg;
+      dotP = (s_nv[3 * t] / w) * (s_cv[3 * t] / w) + (s_nv[3 * t + 1] / w) * (s_cv[3 * t + 1] / w) +
+             (s_nv[3 * t + 2] / w) * (s_cv[3 * t + 2] / w);
+    }
+    const double dauN = m.D * lx - m.alpha * s.x * ly - m.alpha * dotP + m.S * m.r * s.x * (m.nMax - s.x);
+    const double dauC = ly + m.S * (s.x / (1 + s.x) - s.y);
+    double2 o;
+    o.x = dt * dauN + s.x > 0 ? dt * dauN + s.x : 0.0;
+    o.y = dt * dauC + s.y > 0 ? dt * dauC + s.y : 0.0;
+    fn_dst[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Native step.  One wave64 per slice; entry (k, lane) of a slice lives at
+// slice_off + k*64 + lane, so every operator load is one fully coalesced
+// 256-B (idx) or 1-KiB (coef, fp32) wave access; neighbour state is gathered
+// from global memory (L1/L2-resident: a slice's neighbours are a few KB).
+// Workgroups are renumbered so that consecutive slices run on one XCD and share
+// its L2 (workgroups are dealt round-robin over the 8 XCDs).
+// Algorithmic bytes per vertex (fp32, valence 6): 6*(4+16) operator + 8 state
+// read + 8 state write = 136 B (+ gathers served on chip).
+// ---------------------------------------------------------------------------
+template <typename T, bool NT>
+__global__ __launch_bounds__(256) void sell_step_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
+    const uint *__restrict__ slice_off, const uint *__restrict__ idx,
+    const typename Vec<T>::t4 *__restrict__ coef, uint V, uint nslices, uint nblocks, ModelT<T> m) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  // bijective XCD remap: blocks b, b+8, b+16, ... (one XCD) get consecutive slices
+  const uint b = blockIdx.x, q = nblocks >> 3, r = nblocks & 7u, x = b & 7u;
+  const uint lb = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+  const uint slice = lb * 4 + (threadIdx.x >> 6);
+  if (slice >= nslices) return;
+  const uint lane = threadIdx.x & 63u;
+  const uint off = __builtin_amdgcn_readfirstlane(slice_off[slice]);
+  const uint end = __builtin_amdgcn_readfirstlane(slice_off[slice + 1]);
+  const uint v = slice * 64 + lane;
+  const uint vs = v < V ? v : V - 1;
+  const T2 s = src[vs];
+  T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+#pragma unroll 2
+  for (uint e = off + lane; e < end; e += 64) {
+    const uint j = NT ? __builtin_nontemporal_load(&idx[e]) : idx[e];     // read-once streams: do not evict the state
+    const T4 c = NT ? ntload(&coef[e]) : coef[e];
+    const T2 f = src[j];
+    const T dn = f.x - s.x, dc = f.y - s.y;
+    lapn += c.x * dn; lapc += c.x * dc;
+    gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+    gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+  }
+  const T2 o = reaction_update<T>(s, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+  if (v < V) dst[v] = o;
+}
+
+// ---------------------------------------------------------------------------
+// Fused k-step kernel.  One workgroup per tile (pack.cpp:packTileLayout): the tile's owned rows
+// plus k rings of neighbours are staged in LDS (two ping-pong buffers of m[k] pairs), the
+// operator rows of the first m[k-1] local rows are loaded ONCE into registers (thread t holds rows
+// t, t+TPB, ...: R rows x W entries x (float4 coef + 16-bit local column id)), and the workgroup
+// takes up to k time steps before writing its owned rows back: step s recomputes rows
+// [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
+// vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
+// ---------------------------------------------------------------------------
+template <typename T, int TPB, int R, int W, int MINW, bool X, int PRO>
+__global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
+    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
+    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  extern __shared__ __align__(16) unsigned char tile_smem[];
+  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
+  const uint tile = tile0 + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);   // tiles [tile0, tile0 + ntiles)
+  const uint *mt = meta + 16 * (size_t)tile;
+  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], k = mt[4];
+  const uint n0 = mt[5], mk = mt[5 + k];
+  T2 *cur = reinterpret_cast<T2 *>(tile_smem);
+  T2 *nxt = cur + maxLocal;
+  // rows wider than W (irregular meshes): entries W, W+1, ... of all rows of the tile, in LDS
+  T4 *xs_coef = reinterpret_cast<T4 *>(nxt + maxLocal);          // maxLocal is even: 16-B aligned
+  uint *xs_off = reinterpret_cast<uint *>(xs_coef + maxExtra);
+  uint *xs_info = xs_off + maxExtra;                             // [T*R] rows of the register tile
+  uint *xs_ix = xs_info + TPB * R;                               // X: the packed column offsets live here, not in VGPRs
+  constexpr bool IXL = true;                             // packed column offsets in LDS (frees W/2*R VGPRs)
+  const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // X = false: plan without wide rows
+  const uint t = threadIdx.x;
+
+  // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
+  const T4 *__restrict__ tcoef = coef + roff;
+  const uint *__restrict__ tidx = idx2 + (roff >> 1);
+  // Every load below is unconditional with a clamped index (no branch => no wait at a branch
+  // merge), so the whole prologue is in flight at once: R*(W + W/2) operator loads, then the
+  // ghost ids, then the state gathers; the first wait is the one in front of the LDS writes.
+  T4 cf[R][W];
+  uint ix[R][W / 2];
+  constexpr int SU = 4;                                  // state slots per thread per pass
+  uint gi[SU];
+  auto loadGhostIds = [&](uint i0) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      const uint g = (i >= n0 && i < mk) ? i - n0 : 0;   // ghost[] carries one pad element
+      gi[u] = PRO == 3 ? __builtin_nontemporal_load(&ghost[goff + g]) : ghost[goff + g];
+    }
+  };
+  // Issue order = completion order (one in-order counter per wave): the ghost ids go first, so
+  // the dependent state gathers can leave while the operator rows are still streaming in.
+  // PRO (FEM_TILE_PROLOGUE, same-box A/B on the 16M sphere): 0 ids after the operator 219.0;
+  // 1 ids first 220.2; 2 + operator rows as nontemporal loads 222.9; 3 + index streams
+  // nontemporal 224.6-228.7 G DOF-it/s (the read-once streams stop evicting the state, which
+  // is the only data with reuse between tiles and launches).
+  if (PRO >= 1) loadGhostIds(0);
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    const uint r = min(t + TPB * q, rpad - 1);         // rows in [rows, rpad) are zero padding
+#pragma unroll
+    for (int w = 0; w < W / 2; w++)                      // ids < 4096: both halves scale
+      ix[q][w] = (PRO == 3 ? __builtin_nontemporal_load(&tidx[w * rpad + r]) : tidx[w * rpad + r]) * (uint)sizeof(T2);
+  }
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    const uint r = min(t + TPB * q, rpad - 1);
+#pragma unroll
+    for (int w = 0; w < W; w++) cf[q][w] = PRO >= 2 ? ntload(&tcoef[w * rpad + r]) : tcoef[w * rpad + r];
+  }
+  if (X && xcnt) {                                       // tile-uniform
+    for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
+    for (uint i = t; i < xcnt; i += TPB) {
+      xs_coef[i] = tcoef[W * rpad + i];
+      xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
+    }
+  }
+  for (uint i0 = 0; i0 < mk; i0 += SU * TPB) {
+    T2 sv[SU];
+    if (PRO < 1 || i0 > 0) loadGhostIds(i0);
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      sv[u] = src[i < n0 ? base + i : gi[u]];
+    }
+    if (IXL && i0 == 0) {
+#pragma unroll
+      for (int q = 0; q < R; q++)
+#pragma unroll
+        for (int w = 0; w < W / 2; w++) xs_ix[w * (TPB * R) + t + TPB * q] = ix[q][w];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+      const uint i = i0 + t + TPB * u;
+      if (i < mk) cur[i] = sv[u];
+    }
+  }
+  __syncthreads();
+
+  for (int s = 0; s < nsteps; s++) {
+    const uint lim = mt[5 + k - 1 - s];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const uint r = t + TPB * q;
+      if (r < lim) {
+        const T2 self = cur[r];
+        T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+        if constexpr (IXL) {
+#pragma unroll
+          for (int w = 0; w < W / 2; w++) ix[q][w] = xs_ix[w * (TPB * R) + r];
+        }
+#pragma unroll
+        for (int w = 0; w < W / 2; w++) asm volatile("" : "+v"(ix[q][w]));   // keep the unpacking in the loop, not in VGPRs
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+          const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);   // byte offset in the buffer
+          const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
+          const T4 c = cf[q][w];
+          const T dn = f.x - self.x, dc = f.y - self.y;
+          lapn += c.x * dn; lapc += c.x * dc;
+          gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+          gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+        }
+        if (X && xcnt) {                                 // entries W, W+1, ... of a wide row
+          const uint xi = xs_info[r];
+          for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {
+            const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
+            const T4 c = xs_coef[e];
+            const T dn = f.x - self.x, dc = f.y - self.y;
+            lapn += c.x * dn; lapc += c.x * dc;
+            gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+            gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+          }
+        }
+        nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
+    }
+    __syncthreads();
+    T2 *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  for (uint i = t; i < n0; i += TPB) dst[base + i] = cur[i];
+}
+
+
