@@ -110,6 +110,13 @@ def make_scanned_like(nu, edge=0.1, seed=1, flip_fraction=0.1, noise_amp=0.1, hi
                      C.c_int(high_valence))
 
 
+def subdivide(points, tri, levels=1):
+    """1-to-4 midpoint subdivision, `levels` rounds (the upsampler for real scans)"""
+    points, tri = np.ascontiguousarray(points, np.float64), np.ascontiguousarray(tri, np.uint32)
+    return _mesh_out(lib.fem_subdivide, C.c_int(len(points)), C.c_int(len(tri)), _ptr(points, f64p), _ptr(tri, u32p),
+                     C.c_int(levels))
+
+
 def make_strip(nx=11, ny=41, h=0.1):
     return _mesh_out(lib.fem_make_strip, C.c_int(nx), C.c_int(ny), C.c_double(h))
 

@@ -86,6 +86,17 @@ int fem_make_strip(int nx, int ny, double h, int *V, int *F, double **points, fe
   return exportMesh(m, V, F, points, tri);
 }
 
+int fem_subdivide(int V, int F, const double *points, const fem_uint *tri, int levels, int *Vout, int *Fout,
+                  double **points_out, fem_uint **tri_out) {
+  if (V < 0 || F < 0 || (V && !points) || (F && !tri)) return fail(FEM_ERR_INVALID, "fem_subdivide: bad argument");
+  fem::SimpleTriMesh in, out;
+  in.points.assign(points, points + 3 * (size_t)V);
+  in.faces.assign(tri, tri + 3 * (size_t)F);
+  int rc = fem::subdivide(in, levels, out);
+  if (rc != FEM_OK) return fail(rc, "fem_subdivide: 0 <= levels <= 12, manifold input, result below 2^32 vertices");
+  return exportMesh(out, Vout, Fout, points_out, tri_out);
+}
+
 void fem_initial_condition(int V, fem_uint seed, double nMax, double *nFn, double *cFn) {
   fem::initialCondition(V, seed, nMax, nFn, cFn);
 }

@@ -99,6 +99,7 @@ int makeIcosphere(int nu, double edge, SimpleTriMesh &m);
 int makeStrip(int nx, int ny, double h, SimpleTriMesh &m);
 int makeScannedLike(int nu, double edge, uint seed, double flipFraction, double noiseAmp, double highValFraction,
                     int highVal, SimpleTriMesh &m);
+int subdivide(const SimpleTriMesh &in, int levels, SimpleTriMesh &out);
 void initialCondition(int V, uint seed, double nMax, double *nFn, double *cFn);
 
 // Reference device layout (initializeGPUData, main.cpp:207-342), dense host form.

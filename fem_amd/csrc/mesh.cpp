@@ -616,6 +616,48 @@ int makeScannedLike(int nu, double edge, uint seed, double flipFraction, double 
   return FEM_OK;
 }
 
+// Upsampler (BASELINE config 4 speaks of upsampled scans): `levels` rounds of 1-to-4 midpoint
+// subdivision.  New vertices = old vertices, then one per edge in the order of its lower half-edge
+// id; face (a, b, c) becomes (a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca): orientation, the
+// boundary and every old vertex position are kept, colours are interpolated.
+int subdivide(const SimpleTriMesh &in, int levels, SimpleTriMesh &out) {
+  if (levels < 0 || levels > 12) return FEM_ERR_INVALID;
+  SimpleTriMesh cur = in;
+  for (int l = 0; l < levels; l++) {
+    if (cur.H == 0) { const int rc = cur.update_topology(); if (rc != FEM_OK) return rc; }
+    const size_t V = cur.n_vertices(), F = cur.n_faces(), H = (size_t)cur.H, E = H / 2;
+    if (V + E > 0xfffffff0ull || 4 * F > 0x55555550ull) return FEM_ERR_LIMIT;
+    std::vector<uint> mid(H);
+    SimpleTriMesh nxt;
+    nxt.points = cur.points;
+    nxt.points.resize(3 * (V + E));
+    const bool col = cur.colors.size() == cur.points.size() && V > 0;
+    if (col) { nxt.colors = cur.colors; nxt.colors.resize(3 * (V + E)); }
+    uint next = (uint)V;
+    for (size_t h = 0; h < H; h++) {
+      const size_t o = (size_t)cur.opp[h];
+      if (o < h) { mid[h] = mid[o]; continue; }
+      const uint a = cur.he_from[h], b = cur.he_to[h];
+      for (int k = 0; k < 3; k++) {
+        nxt.points[3 * (size_t)next + k] = 0.5 * (cur.points[3 * (size_t)a + k] + cur.points[3 * (size_t)b + k]);
+        if (col) nxt.colors[3 * (size_t)next + k] = (unsigned char)((cur.colors[3 * (size_t)a + k] + cur.colors[3 * (size_t)b + k] + 1) / 2);
+      }
+      mid[h] = next++;
+    }
+    nxt.faces.resize(12 * F);
+    for (size_t f = 0; f < F; f++) {
+      const uint a = cur.faces[3 * f], b = cur.faces[3 * f + 1], c = cur.faces[3 * f + 2];
+      const uint ab = mid[3 * f], bc = mid[3 * f + 1], ca = mid[3 * f + 2];
+      const uint t[12] = {a, ab, ca, ab, b, bc, ca, bc, c, ab, bc, ca};
+      std::copy(t, t + 12, nxt.faces.begin() + 12 * f);
+    }
+    cur = std::move(nxt);
+  }
+  out = std::move(cur);
+  out.H = 0;
+  return FEM_OK;
+}
+
 // nx x ny planar strip tilted 45 degrees in y-z, vertex id = ix*ny + iy, faces
 // (v, v+ny, v+ny+1), (v, v+ny+1, v+1) -- the shape of ResultantPattern.off
 // (ResultantPattern.off:1-4,44,454-457).

@@ -102,6 +102,11 @@ int fem_off_write(const char *path, int V, int F, const double *points, const fe
  * h=0.1 reproduces its geometry). */
 int fem_make_icosphere(int nu, double edge, int *V, int *F, double **points, fem_uint **tri);
 int fem_make_strip(int nx, int ny, double h, int *V, int *F, double **points, fem_uint **tri);
+/* Upsampler for real scans (BASELINE config 4: "upsampled Stanford Lucy/bunny"): `levels` rounds of
+ * 1-to-4 midpoint subdivision (V' = V + E, F' = 4F per round); old vertices keep index and
+ * position, orientation and boundary are kept.  Outputs are fem_free'd by the caller. */
+int fem_subdivide(int V, int F, const double *points, const fem_uint *tri, int levels, int *Vout, int *Fout,
+                  double **points_out, fem_uint **tri_out);
 /* "scanned-like" irregular closed surface for BASELINE config 4 (no scan data is available):
  * the icosphere with flip_fraction * E seeded random edge flips, high_valence_fraction * V vertices
  * driven to valence >= high_valence by fans of flips, and radial noise of noise_amp edge lengths */

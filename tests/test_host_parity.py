@@ -316,3 +316,31 @@ def test_graph_partitioner():
     assert fm.partition(k, npart=gr).cut < 0.8 * fm.partition(k, npart=rcb).cut
     with pytest.raises(fa.FemError):
         m.partition_vertices(m.V + 1, "graph")
+
+
+def test_subdivide_upsampler():
+    """1-to-4 midpoint subdivision: counts, old vertices kept, area kept, orientation and
+    boundary kept, still manifold; COFF pattern file upsampled two levels"""
+    pts, tri = fa.make_strip(5, 7, 0.1)
+    m0 = fa.Mesh(pts, tri).init_stats(fa.PREC_F64)
+    E = m0.H // 2
+    p1, t1 = fa.subdivide(pts, tri, 1)
+    assert len(p1) == len(pts) + E and len(t1) == 4 * len(tri)
+    assert np.array_equal(p1[:len(pts)], pts)
+    m1 = fa.Mesh(p1, t1).init_stats(fa.PREC_F64)
+    assert abs(m1.stats()["meshArea"].sum() - m0.stats()["meshArea"].sum()) <= 1e-12
+    assert m1.H - 3 * m1.F == 2 * (m0.H - 3 * m0.F)                  # boundary edges doubled
+    n0 = np.cross(pts[tri[:, 1]] - pts[tri[:, 0]], pts[tri[:, 2]] - pts[tri[:, 0]])
+    n1 = np.cross(p1[t1[:, 1]] - p1[t1[:, 0]], p1[t1[:, 2]] - p1[t1[:, 0]])
+    assert np.allclose(n1, np.repeat(n0, 4, axis=0) / 4)               # same orientation, quarter area
+    ps, ts = fa.make_icosphere(3, 0.1)
+    p2, t2 = fa.subdivide(ps, ts, 2)
+    assert len(t2) == 16 * len(ts) and len(p2) - len(t2) // 2 == 2     # Euler characteristic of the sphere
+    deg = np.diff(fa.Mesh(p2, t2).topology()["rowptr"])
+    assert (deg == 5).sum() == 12 and (deg == 6).sum() == len(p2) - 12
+    p0, t0 = fa.subdivide(ps, ts, 0)
+    assert np.array_equal(p0, ps) and np.array_equal(t0, ts)
+    bad = ts.copy()
+    bad[0] = bad[0][::-1]
+    with pytest.raises(fa.FemError):
+        fa.subdivide(ps, bad, 1)
