@@ -379,19 +379,21 @@ class Shard:
 class Plan:
     """Native plan: sliced-ELL operator + ping-pong state on the device."""
 
-    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None, part=None, ksteps=0, assemble=False):
+    def __init__(self, ordered, precision=PREC_F32, model=None, shard=None, part=None, ksteps=0, assemble=False,
+                 implicit=False):
         """ksteps > 0 (with part = the Partition of `ordered`): fused-tile layout, up to ksteps time
         steps per launch; otherwise the sliced-ELL layout, one step per launch.
-        assemble=True keeps connectivity/positions on the device for fem_plan_assemble."""
+        assemble=True keeps connectivity/positions on the device for fem_plan_assemble;
+        implicit=True (sliced-ELL plan of a whole mesh) enables run_imex."""
         h = vp()
         mp = C.byref(model) if model is not None else None
         self.ksteps = ksteps
         self.F = ordered.F
-        if assemble:
+        if assemble or implicit:
             _check(lib.fem_plan_create_ex(ordered.h, C.c_int(part.n if part is not None else 0),
                                           _ptr(part.node_parts, u32p) if part is not None else None,
                                           shard.h if shard is not None else None, C.c_int(precision), mp,
-                                          C.c_int(ksteps), C.c_uint(1), C.byref(h)))
+                                          C.c_int(ksteps), C.c_uint((1 if assemble else 0) | (2 if implicit else 0)), C.byref(h)))
             self.V = shard.n_local if shard is not None else ordered.V
         elif ksteps > 0:
             _check(lib.fem_plan_create_tiled(ordered.h, C.c_int(part.n), _ptr(part.node_parts, u32p),
@@ -488,6 +490,16 @@ class Plan:
     def run(self, nsteps, dt, model=None, stream=None):
         mp = C.byref(model) if model is not None else None
         _check(lib.fem_plan_run(self.h, C.c_int(nsteps), C.c_double(dt), mp, vp(stream or 0)))
+
+    def run_imex(self, nsteps, dt, model=None, cg_iterations=20, stream=None):
+        """semi-implicit steps: diffusion implicit (preconditioned CG), reaction/chemotaxis explicit"""
+        mp = C.byref(model) if model is not None else None
+        _check(lib.fem_plan_run_imex(self.h, C.c_int(nsteps), C.c_double(dt), mp, C.c_int(cg_iterations), vp(stream or 0)))
+
+    def imex_residual(self):
+        a, b = C.c_double(), C.c_double()
+        _check(lib.fem_plan_imex_residual(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def operator_bytes(self):
         return lib.fem_plan_operator_bytes(self.h)

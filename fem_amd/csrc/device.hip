@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,7 @@ struct ModelD { double nMax, D, r, alpha, S; };
 #include "kernels_step.hpp"
 #include "kernels_assembly.hpp"
 #include "kernels_output.hpp"
+#include "kernels_implicit.hpp"
 
 template <typename T> struct DevBuf {
   T *p = nullptr;
@@ -108,6 +110,10 @@ struct fem_plan {
   DevBuf<fem_uint> tri0, tri1, tri2, topo, rowg;
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
   double *maxedge = nullptr, *blockmax = nullptr;
+  // semi-implicit stepping (FEM_PLAN_IMPLICIT): lumped mass and row sums of w per row; CG work vectors
+  bool can_imex = false;
+  void *mass = nullptr, *wsum = nullptr, *ix_w = nullptr, *ix_r = nullptr, *ix_p = nullptr, *ix_q = nullptr;
+  double *ix_partial = nullptr, *ix_sc = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
   void *state[2] = {nullptr, nullptr};   // deviations from (base_n, base_c), interleaved
   int cur = 0;
@@ -186,6 +192,57 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
                      p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->txinfo.p, first, count, p->maxLocal, p->maxExtra,
                      nsteps, m);
   return hipSuccess;
+}
+
+// ---- semi-implicit stepping ------------------------------------------------------------------------
+
+template <typename T>
+static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, int iters, hipStream_t st) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  const size_t V = p->V;
+  const fem_uint nbv = (fem_uint)((V + 255) / 256), nbs = p->nblocks;
+  if (!p->ix_r) {
+    HIP_TRY(hipMalloc(&p->ix_r, sizeof(T2) * V));
+    HIP_TRY(hipMalloc(&p->ix_p, sizeof(T2) * V));
+    HIP_TRY(hipMalloc(&p->ix_q, sizeof(T2) * V));
+    HIP_TRY(hipMalloc((void **)&p->ix_partial, 16 * (size_t)std::max(nbv, nbs)));
+    HIP_TRY(hipMalloc((void **)&p->ix_sc, 16 * sizeof(double)));
+    HIP_TRY(hipMemset(p->ix_sc, 0, 16 * sizeof(double)));
+    HIP_TRY(hipMalloc(&p->ix_w, sizeof(T) * (p->entries ? p->entries : 1)));
+    hipLaunchKernelGGL(imex_weights_kernel<T>, dim3((unsigned)((p->entries + 255) / 256)), dim3(256), 0, st, (const T4 *)p->coef,
+                       (T *)p->ix_w, p->entries);
+  }
+  const ModelT<T> m = {(T)(model->nMax - p->base_n), (T)model->D, (T)model->r, (T)model->alpha, (T)model->S, (T)dt, (T)p->base_n,
+                       (T)(1.0 / (1.0 + p->base_n))};
+  const T dtDn = (T)(dt * model->D), dtDc = (T)dt;
+  const T *mass = (const T *)p->mass, *wsum = (const T *)p->wsum;
+  for (int s = 0; s < nsteps; s++) {
+    const T2 *u = (const T2 *)p->state[p->cur];
+    T2 *x = (T2 *)p->state[p->cur ^ 1];
+    // b = u + dt * (explicit terms); x0 = b
+    hipLaunchKernelGGL((sell_step_kernel<T, true, true>), dim3(nbs), dim3(256), 0, st, u, x, p->slice_off.p, p->idx.p,
+                       (const T4 *)p->coef, p->V, p->nslices, p->nblocks, m);
+    // r0 = M b - A b, p0 = r0 / diag, rz
+    hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)x, (T2 *)p->ix_q, (T2 *)p->ix_r, (T2 *)p->ix_p,
+                       p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, p->nslices, p->nblocks, dtDn, dtDc, 1, p->ix_partial);
+    hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbs, p->ix_sc, 0);
+    for (int it = 0; it < iters; it++) {
+      hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)p->ix_p, (T2 *)p->ix_q, (T2 *)p->ix_r, (T2 *)p->ix_p,
+                         p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, p->nslices, p->nblocks, dtDn, dtDc, 0, p->ix_partial);
+      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbs, p->ix_sc, 1);
+      hipLaunchKernelGGL(imex_update_kernel<T>, dim3(nbv), dim3(256), 0, st, x, (T2 *)p->ix_r, (const T2 *)p->ix_p, (const T2 *)p->ix_q,
+                         mass, wsum, p->V, dtDn, dtDc, (const double *)p->ix_sc, p->ix_partial);
+      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbv, p->ix_sc, 2);
+      if (it + 1 < iters)
+        hipLaunchKernelGGL(imex_direction_kernel<T>, dim3(nbv), dim3(256), 0, st, (T2 *)p->ix_p, (const T2 *)p->ix_r, mass, wsum, p->V,
+                           dtDn, dtDc, (const double *)p->ix_sc);
+    }
+    hipLaunchKernelGGL(imex_clamp_kernel<T>, dim3(nbv), dim3(256), 0, st, x, p->V, (T)p->base_n, (T)p->base_c);
+    p->cur ^= 1;
+  }
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
 }
 
 extern "C" {
@@ -344,6 +401,7 @@ void fem_plan_destroy(fem_plan *p) {
   p->tmeta.release(); p->tghost.release(); p->tidx2.release(); p->txinfo.release();
   p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release(); p->rowg.release();
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
+  for (void *q : {p->mass, p->wsum, p->ix_w, p->ix_r, p->ix_p, p->ix_q, (void *)p->ix_partial, (void *)p->ix_sc}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
@@ -355,6 +413,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64) || ksteps < 0 || ksteps > 8)
     return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
   if (ksteps > 0 && (!node_parts || n < 1)) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partition ranges missing");
+  if ((flags & FEM_PLAN_IMPLICIT) && (ksteps > 0 || shard))
+    return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT needs a sliced-ELL plan of a whole mesh (ksteps = 0, no shard)");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");
@@ -461,6 +521,18 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     ok(hipMalloc(&p->pos, 4 * sb * p->Vg)) && ok(hipMalloc(&p->pos0, 4 * sb * p->Vg)) &&
     ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8)) &&
     ok(hipMalloc((void **)&p->blockmax, 8 * (size_t)(std::max<size_t>(ksteps > 0 ? TL.ntiles : (L.nslices + 3) / 4, 1))));
+  }
+  if (e == hipSuccess && (flags & FEM_PLAN_IMPLICIT)) {
+    // lumped mass a_v and sum_j w_vj of every row (MeshStats: areaPerVtx, -wVtx)
+    std::vector<double> hm(op.V), hw(op.V);
+    for (fem::uint r = 0; r < op.V; r++) { hm[r] = ordered->stats.areaPerVtx[op.rowg[r]]; hw[r] = -ordered->stats.wVtx[op.rowg[r]]; }
+    auto uploadVec = [&](void **dev, const std::vector<double> &h) {
+      if (!ok(hipMalloc(dev, sb * h.size()))) return;
+      if (precision == FEM_PREC_F32) { std::vector<float> f(h.begin(), h.end()); ok(hipMemcpy(*dev, f.data(), 4 * f.size(), hipMemcpyHostToDevice)); }
+      else ok(hipMemcpy(*dev, h.data(), 8 * h.size(), hipMemcpyHostToDevice));
+    };
+    uploadVec(&p->mass, hm); uploadVec(&p->wsum, hw);
+    p->can_imex = e == hipSuccess;
   }
   if (e == hipSuccess && shard)
     ok(p->send_idx.alloc(shard->send_idx.size())) && (shard->send_idx.empty() || ok(p->send_idx.upload(shard->send_idx.data())));
@@ -631,6 +703,27 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
     p->cur ^= 1;
   }
   HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+// ---- semi-implicit stepping (runImex above) ---------------------------------------------------
+
+int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream) {
+  if (!p || nsteps < 0 || cg_iterations < 1 || cg_iterations > 10000) return fail(FEM_ERR_INVALID, "fem_plan_run_imex: bad argument");
+  if (!p->can_imex) return fail(FEM_ERR_INVALID, "fem_plan_run_imex: plan was not created with FEM_PLAN_IMPLICIT");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  return p->precision == FEM_PREC_F32 ? runImex<float>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream)
+                                      : runImex<double>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream);
+}
+
+int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c) {
+  if (!p || !p->ix_sc) return fail(FEM_ERR_INVALID, "fem_plan_imex_residual: no semi-implicit step has run");
+  double sc[16];
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(sc, p->ix_sc, sizeof sc, hipMemcpyDeviceToHost));
+  if (rel_n) *rel_n = sc[6] > 0 ? std::sqrt(sc[8] / sc[6]) : 0.0;
+  if (rel_c) *rel_c = sc[7] > 0 ? std::sqrt(sc[9] / sc[7]) : 0.0;
   return FEM_OK;
 }
 

@@ -28,6 +28,21 @@ __device__ __forceinline__ typename Vec<T>::t2 reaction_update(typename Vec<T>::
   return o;
 }
 
+// IMEX variant (semi-implicit stepping, kernels_implicit.hpp): the reaction and chemotaxis terms
+// explicitly, the two diffusion terms (D lap n, lap c) left to the implicit solve; no clamp here.
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t2 imex_rhs_update(typename Vec<T>::t2 s, T lapc, T gnx, T gny, T gnz, T gcx,
+                                                               T gcy, T gcz, const ModelT<T> &m) {
+  const T n = m.bn + s.x;
+  const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
+  const T dauN = -m.alpha * n * lapc - m.alpha * dotP + m.S * m.r * n * (m.nMaxOff - s.x);
+  const T dauC = m.S * (s.x * m.cden / (1 + n) - s.y);
+  typename Vec<T>::t2 o;
+  o.x = m.dt * dauN + s.x;
+  o.y = m.dt * dauC + s.y;
+  return o;
+}
+
 // streaming (read-once) 16/32-byte load: keeps the operator rows from evicting the state lines in L2
 __device__ __forceinline__ float4 ntload(const float4 *p) {
   typedef float v4f __attribute__((ext_vector_type(4)));

@@ -1,0 +1,152 @@
+// kernels_implicit.hpp -- semi-implicit (IMEX Euler) stepping on the sliced-ELL layout (the
+// reference only hints at it: unused Jacobian scaffolding, mesh_function.cpp:490-586).
+// Included by device.hip inside its anonymous namespace.
+//
+// One time step:  b = u + dt * (reaction + chemotaxis terms at u)          [sell_step_kernel<.., IMEX>]
+//                 (I - dt D_f L) u' = b   for f = n (D_n = D) and f = c (D_c = 1),   then clamp at 0,
+// L = the cotangent Laplacian with lumped mass (row v: sum_j w_vj (x_j - x_v)).  M (I - dt D L) with
+// M = diag(areaPerVtx) is symmetric positive definite (a_v w_vj = half the cotangent sum of the edge), so
+// the system M b = A x is solved by Jacobi-preconditioned conjugate gradients, both fields at once with
+// separate scalars.  Everything stays on the device: the dot products are reduced to per-workgroup
+// partials (fixed order, bit-reproducible) and finished by a one-workgroup kernel that also forms
+// alpha / beta, so a step is a fixed sequence of launches with no host synchronisation.
+#pragma once
+
+// q = A p (one wave64 per slice, as sell_step_kernel) and the partials of p.q
+//   mode 0: plain;  mode 1 (first call of a solve, p = x0 = b): r = M b - A b, p = r / diag, partials of r.(r/diag)
+template <typename T>
+__global__ __launch_bounds__(256) void imex_apply_kernel(const typename Vec<T>::t2 *__restrict__ x, typename Vec<T>::t2 *__restrict__ q,
+                                                         typename Vec<T>::t2 *__restrict__ r, typename Vec<T>::t2 *__restrict__ pout,
+                                                         const uint *__restrict__ slice_off, const uint *__restrict__ idx,
+                                                         const T *__restrict__ wgt, const T *__restrict__ mass,
+                                                         const T *__restrict__ wsum, uint V, uint nslices, uint nblocks, T dtDn, T dtDc,
+                                                         int mode, double *__restrict__ partial) {
+  typedef typename Vec<T>::t2 T2;
+  const uint b = blockIdx.x, q8 = nblocks >> 3, r8 = nblocks & 7u, xcd = b & 7u;
+  const uint lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
+  const uint slice = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  double d0 = 0, d1 = 0;
+  if (slice < nslices) {
+    const uint off = __builtin_amdgcn_readfirstlane(slice_off[slice]);
+    const uint end = __builtin_amdgcn_readfirstlane(slice_off[slice + 1]);
+    const uint v = slice * 64 + lane, vs = v < V ? v : V - 1;
+    const T2 s = x[vs];
+    T ln = 0, lc = 0;
+#pragma unroll 2
+    for (uint e = off + lane; e < end; e += 64) {
+      const uint j = __builtin_nontemporal_load(&idx[e]);
+      const T w = __builtin_nontemporal_load(&wgt[e]);
+      const T2 f = x[j];
+      ln += w * (f.x - s.x); lc += w * (f.y - s.y);
+    }
+    if (v < V) {
+      const T a = mass[v];
+      if (mode == 0) {
+        T2 o;
+        o.x = a * (s.x - dtDn * ln); o.y = a * (s.y - dtDc * lc);
+        q[v] = o;
+        d0 = (double)s.x * (double)o.x; d1 = (double)s.y * (double)o.y;
+      } else {
+        const T ws = wsum[v];
+        T2 rr, pp;
+        rr.x = a * dtDn * ln; rr.y = a * dtDc * lc;                 // M b - A b
+        pp.x = rr.x / (a * (1 + dtDn * ws)); pp.y = rr.y / (a * (1 + dtDc * ws));
+        r[v] = rr; pout[v] = pp;
+        d0 = (double)rr.x * (double)pp.x; d1 = (double)rr.y * (double)pp.y;
+      }
+    }
+  }
+  __shared__ double sp[8];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+  if (lane == 0) { sp[2 * (threadIdx.x >> 6)] = d0; sp[2 * (threadIdx.x >> 6) + 1] = d1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * (size_t)lb] = (sp[0] + sp[2]) + (sp[4] + sp[6]);
+    partial[2 * (size_t)lb + 1] = (sp[1] + sp[3]) + (sp[5] + sp[7]);
+  }
+}
+
+// the Laplacian weights alone (4 or 8 B per entry instead of the 16/32-B coefficient records)
+template <typename T>
+__global__ __launch_bounds__(256) void imex_weights_kernel(const typename Vec<T>::t4 *__restrict__ coef, T *__restrict__ wgt, size_t n) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e < n) wgt[e] = coef[e].x;
+}
+
+// scalars sc[]: 0,1 rz   2,3 alpha   4,5 beta   6,7 r0z0 (first residual norms)   8,9 last rz
+//   what 0: rz = sum;  r0z0 = sum                        (after the mode-1 apply)
+//   what 1: alpha = rz / sum (sum = p.q)                  (after a mode-0 apply)
+//   what 2: beta = sum / rz;  rz = sum                    (after the update)
+__global__ __launch_bounds__(256) void imex_scalar_kernel(const double *__restrict__ partial, uint n, double *__restrict__ sc, int what) {
+  __shared__ double sp[8];
+  double d0 = 0, d1 = 0;
+  for (uint i = threadIdx.x; i < n; i += 256) { d0 += partial[2 * (size_t)i]; d1 += partial[2 * (size_t)i + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+  if ((threadIdx.x & 63) == 0) { sp[2 * (threadIdx.x >> 6)] = d0; sp[2 * (threadIdx.x >> 6) + 1] = d1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double s0 = (sp[0] + sp[2]) + (sp[4] + sp[6]), s1 = (sp[1] + sp[3]) + (sp[5] + sp[7]);
+    if (what == 0) { sc[0] = s0; sc[1] = s1; sc[6] = s0; sc[7] = s1; sc[8] = s0; sc[9] = s1; }
+    else if (what == 1) { sc[2] = s0 > 0 ? sc[0] / s0 : 0.0; sc[3] = s1 > 0 ? sc[1] / s1 : 0.0; }
+    else { sc[4] = sc[0] > 0 ? s0 / sc[0] : 0.0; sc[5] = sc[1] > 0 ? s1 / sc[1] : 0.0; sc[0] = s0; sc[1] = s1; sc[8] = s0; sc[9] = s1; }
+  }
+}
+
+// x += alpha p;  r -= alpha q;  partials of r.(r/diag)
+template <typename T>
+__global__ __launch_bounds__(256) void imex_update_kernel(typename Vec<T>::t2 *__restrict__ x, typename Vec<T>::t2 *__restrict__ r,
+                                                          const typename Vec<T>::t2 *__restrict__ p, const typename Vec<T>::t2 *__restrict__ q,
+                                                          const T *__restrict__ mass, const T *__restrict__ wsum, uint V, T dtDn, T dtDc,
+                                                          const double *__restrict__ sc, double *__restrict__ partial) {
+  typedef typename Vec<T>::t2 T2;
+  const uint v = blockIdx.x * 256 + threadIdx.x;
+  double d0 = 0, d1 = 0;
+  if (v < V) {
+    const T a0 = (T)sc[2], a1 = (T)sc[3];
+    T2 xv = x[v], rv = r[v];
+    const T2 pv = p[v], qv = q[v];
+    xv.x += a0 * pv.x; xv.y += a1 * pv.y;
+    rv.x -= a0 * qv.x; rv.y -= a1 * qv.y;
+    x[v] = xv; r[v] = rv;
+    const T a = mass[v], ws = wsum[v];
+    d0 = (double)rv.x * (double)(rv.x / (a * (1 + dtDn * ws)));
+    d1 = (double)rv.y * (double)(rv.y / (a * (1 + dtDc * ws)));
+  }
+  __shared__ double sp[8];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+  if ((threadIdx.x & 63) == 0) { sp[2 * (threadIdx.x >> 6)] = d0; sp[2 * (threadIdx.x >> 6) + 1] = d1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * (size_t)blockIdx.x] = (sp[0] + sp[2]) + (sp[4] + sp[6]);
+    partial[2 * (size_t)blockIdx.x + 1] = (sp[1] + sp[3]) + (sp[5] + sp[7]);
+  }
+}
+
+// p = r / diag + beta p
+template <typename T>
+__global__ __launch_bounds__(256) void imex_direction_kernel(typename Vec<T>::t2 *__restrict__ p, const typename Vec<T>::t2 *__restrict__ r,
+                                                             const T *__restrict__ mass, const T *__restrict__ wsum, uint V, T dtDn,
+                                                             T dtDc, const double *__restrict__ sc) {
+  const uint v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  const T b0 = (T)sc[4], b1 = (T)sc[5], a = mass[v], ws = wsum[v];
+  typename Vec<T>::t2 pv = p[v];
+  const typename Vec<T>::t2 rv = r[v];
+  pv.x = rv.x / (a * (1 + dtDn * ws)) + b0 * pv.x;
+  pv.y = rv.y / (a * (1 + dtDc * ws)) + b1 * pv.y;
+  p[v] = pv;
+}
+
+// max(0, .) of the step law on deviation-form state (FEM_common.cu:164-165)
+template <typename T>
+__global__ __launch_bounds__(256) void imex_clamp_kernel(typename Vec<T>::t2 *__restrict__ x, uint V, T bn, T bc) {
+  const uint v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  typename Vec<T>::t2 s = x[v];
+  s.x = s.x + bn > 0 ? s.x : -bn;
+  s.y = s.y + bc > 0 ? s.y : -bc;
+  x[v] = s;
+}

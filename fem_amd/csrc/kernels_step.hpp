@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
 // Algorithmic bytes per vertex (fp32, valence 6): 6*(4+16) operator + 8 state
 // read + 8 state write = 136 B (+ gathers served on chip).
 // ---------------------------------------------------------------------------
-template <typename T, bool NT>
+template <typename T, bool NT, bool IMEX = false>
 __global__ __launch_bounds__(256) void sell_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ slice_off, const uint *__restrict__ idx,
@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
     gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
     gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
   }
-  const T2 o = reaction_update<T>(s, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+  const T2 o = IMEX ? imex_rhs_update<T>(s, lapc, gnx, gny, gnz, gcx, gcy, gcz, m)
+                    : reaction_update<T>(s, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
   if (v < V) dst[v] = o;
 }
 

@@ -238,6 +238,7 @@ int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_p
  * be re-assembled there (fem_plan_assemble) -- initMeshStats on the GPU, mesh_function.cpp:27-67.
  * ksteps = 0: sliced-ELL layout; n/node_parts may then be 0/NULL. */
 #define FEM_PLAN_DEVICE_ASSEMBLY 1u
+#define FEM_PLAN_IMPLICIT 2u          /* sliced-ELL plan of a whole mesh: enables fem_plan_run_imex */
 int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                        const fem_shard *shard, int precision, const fem_model *model, int ksteps,
                        unsigned flags, fem_plan **out);
@@ -281,6 +282,17 @@ int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn);
 /* nsteps explicit Euler steps, ping-ponging the plan's two buffers; async on
  * `stream`.  One call = the reference's timed loop body (main.cpp:558-562). */
 int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream);
+/* Semi-implicit (IMEX Euler) steps -- no counterpart in the reference, which only hints at implicit
+ * stepping (unused Jacobian scaffolding, mesh_function.cpp:490-586): reaction and
+ * chemotaxis terms explicit, the diffusion terms implicit,
+ *   (I - dt D L) n' = n + dt (-alpha n L c - alpha Gn.Gc + S r n (nMax - n)),
+ *   (I - dt L)   c' = c + dt S (n/(1+n) - c),   then max(0, .),
+ * each solved by `cg_iterations` Jacobi-preconditioned conjugate-gradient iterations on the
+ * mass-weighted (symmetric positive definite) system, started from the right-hand side; all on the
+ * device, no host synchronisation.  Plan must carry FEM_PLAN_IMPLICIT.  fem_plan_imex_residual:
+ * preconditioned residual norm of the last solve relative to its first one (synchronises). */
+int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
+int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c);
 /* device pointer of the current state buffer (interleaved (n - base_n,
  * c - base_c) pairs of the plan's scalar type), its vertex count, bytes per
  * scalar and the two base values */

@@ -1,0 +1,96 @@
+"""Semi-implicit (IMEX Euler) stepping on the device.  The reference has no such
+path (only unused Jacobian scaffolding, mesh_function.cpp:490-586), so there is nothing of the
+reference's to be at parity with: the checker is an independent scipy restatement of the scheme
+documented in include/fem_hip.h (sparse direct solves), built on the oracle's assembled operator."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+import fem_amd as fa
+import oracle_lib as ol
+from helpers import rel_l2, scan_case, smooth_ic, sphere_case, stable_dt, strip_case
+
+pytestmark = pytest.mark.gpu
+
+
+def scipy_imex(st, topo, n, c, dt, steps, model):
+    """(I - dt D L) n' = n + dt(-a n Lc - a Gn.Gc + S r n (nMax - n)); (I - dt L) c' = c + dt S (n/(1+n) - c)"""
+    nMax, D, r, alpha, S = model
+    V = topo.V
+    rp, col = topo.rowptr, topo.col
+    w = np.asarray(st.wHej)[topo.row_he]
+    row = np.repeat(np.arange(V), np.diff(rp))
+    L = sp.csr_matrix((w, (row, col)), shape=(V, V)) + sp.diags(np.asarray(st.wVtx))
+    I = sp.identity(V, format="csc")
+    solve_n = spla.factorized((I - dt * D * L).tocsc())
+    solve_c = spla.factorized((I - dt * L).tocsc())
+    for _ in range(steps):
+        lapc = L @ c
+        gn = st.vertex_gradients(st.face_gradients(n))
+        gc = st.vertex_gradients(st.face_gradients(c))
+        bn = n + dt * (-alpha * n * lapc - alpha * np.einsum("ij,ij->i", gn, gc) + S * r * n * (nMax - n))
+        bc = c + dt * S * (n / (1 + n) - c)
+        n, c = np.maximum(solve_n(bn), 0), np.maximum(solve_c(bc), 0)
+    return n, c
+
+
+@pytest.mark.parametrize("make,nparts,factor", [(lambda n: sphere_case(16, n), 6, 1.0), (lambda n: sphere_case(16, n), 6, 8.0),
+                                                (lambda n: strip_case(n), 3, 4.0), (lambda n: scan_case(16, n), 5, 6.0)])
+def test_imex_matches_scipy(make, nparts, factor):
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_F64)
+    st = case.ostats(ol.F64)
+    dt = factor * stable_dt(st, case.model, safety=1.0)        # factor x the explicit diffusion limit scale
+    n0, c0 = smooth_ic(case.pts)
+    model = case.model.as_array()
+    n_ref, c_ref = scipy_imex(st, case.topo, n0, c0, dt, 5, model)
+    plan = fa.Plan(case.mesh, fa.PREC_F64, implicit=True)
+    plan.set_state(n0, c0)
+    plan.run_imex(5, dt, case.model, cg_iterations=60)
+    n, c = plan.get_state()
+    assert max(plan.imex_residual()) <= 1e-9
+    assert rel_l2(n, n_ref) <= 1e-9 and rel_l2(c, c_ref) <= 1e-9
+    # fp32 plan, fewer iterations
+    plan32 = fa.Plan(case.mesh, fa.PREC_F32, implicit=True)
+    plan32.set_state(n0, c0)
+    plan32.run_imex(5, dt, case.model, cg_iterations=25)
+    n32, c32 = plan32.get_state()
+    assert rel_l2(n32, n_ref) <= 1e-5 and rel_l2(c32, c_ref) <= 1e-5
+
+
+def test_imex_is_stable_where_explicit_is_not():
+    """pure diffusion (alpha = r = 0) with a time step 40x the explicit limit: the explicit step
+    blows up, the semi-implicit one decays towards the mean and conserves the mass-weighted mean"""
+    case = sphere_case(24, 8)
+    case.mesh.init_stats(fa.PREC_F64)
+    st = case.ostats(ol.F64)
+    m = fa.default_model()
+    m.alpha, m.r, m.S = 0.0, 0.0, 0.0
+    dt = 40 * stable_dt(st, m, safety=1.0)
+    rng = np.random.default_rng(2)
+    n0 = 1 + 0.01 * rng.standard_normal(case.V)
+    c0 = 0.5 + 0.01 * rng.standard_normal(case.V)
+    plan = fa.Plan(case.mesh, fa.PREC_F64, implicit=True)
+    plan.set_state(n0, c0)
+    plan.run_imex(10, dt, m, cg_iterations=80)
+    n, c = plan.get_state()
+    area = np.asarray(st.areaPerVtx)
+    assert np.std(n) < 0.2 * np.std(n0) and np.std(c) < 0.05 * np.std(c0)
+    assert abs((area * n).sum() - (area * n0).sum()) <= 1e-10 * area.sum()
+    assert abs((area * c).sum() - (area * c0).sum()) <= 1e-10 * area.sum()
+    plan.set_state(n0, c0)
+    plan.run(10, dt, m)
+    ne, _ = plan.get_state()
+    assert not np.isfinite(ne).all() or np.std(ne) > 10 * np.std(n0)
+
+
+def test_imex_requires_flag_and_layout():
+    case = sphere_case(6, 2)
+    case.mesh.init_stats(fa.PREC_F64)
+    with pytest.raises(fa.FemError, match="FEM_PLAN_IMPLICIT"):
+        fa.Plan(case.mesh, fa.PREC_F64).run_imex(1, 1e-3)
+    with pytest.raises(fa.FemError):
+        fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=2, implicit=True)
+    with pytest.raises(fa.FemError):
+        fa.Plan(case.mesh, fa.PREC_F64, implicit=True).imex_residual()
