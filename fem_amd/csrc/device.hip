@@ -265,9 +265,11 @@ int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_
       vw_pitchInBytes % sizeof(double) || vv_pitchInBytes % sizeof(fem_uint) ||
       vws_pitchInBytes % sizeof(double) || he_pitchInBytes % sizeof(fem_float4))
     return fail(FEM_ERR_INVALID, "fem_step: pitch not a multiple of the element size");
-  const size_t lds = (size_t)max_part_vertices * 32;         // main.cpp:369
-  if (max_part_vertices == 0 || lds > 160 * 1024)
-    return fail(FEM_ERR_LIMIT, "fem_step: partition too large for the LDS accumulators (<= 5120 vertices)");
+  // corner lists + per-face gradients in LDS (ref_step_kernel): 8 B per vertex + 36 B per face slot
+  const size_t fpitch = fv_pitchInBytes / sizeof(fem_uint);
+  const size_t lds = (size_t)max_part_vertices * 8 + fpitch * 36 + 8;
+  if (max_part_vertices == 0 || lds > 160 * 1024 - 2048)
+    return fail(FEM_ERR_LIMIT, "fem_step: partition too large for the LDS work area (8 B per vertex + 36 B per face slot <= 158 KiB)");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   ModelD m = {model->nMax, model->D, model->r, model->alpha, model->S};
@@ -279,7 +281,7 @@ int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_
                      nbr, vtxW, vw_pitchInBytes / (fem_uint)sizeof(double), vertex_weights,
                      vv_pitchInBytes / (fem_uint)sizeof(fem_uint), vws_pitchInBytes / (fem_uint)sizeof(double),
                      vv_size, (const float4 *)grads, he_pitchInBytes / (fem_uint)sizeof(fem_float4), parts_n,
-                     block_face_count, dt, m);
+                     block_face_count, dt, max_part_vertices, m);
   HIP_TRY(hipGetLastError());
   return FEM_OK;
 }

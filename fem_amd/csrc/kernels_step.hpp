@@ -4,13 +4,20 @@
 #pragma once
 
 // ---------------------------------------------------------------------------
-// Reference-layout step (FEM_common.cu:82-166).  Differences from the reference
-// kernel, none of them in the arithmetic: all loops are block-strided, so no
-// thread leaves before a barrier and a partition may hold more faces or
-// vertices than the block has threads (the reference returns early at :99-100
-// and :138-139); the double accumulator uses the LDS f64 add instead of a CAS
-// loop (:15-31).
-// LDS: wg[size] double, then nvGrads[3*size], cvGrads[3*size] float = 32 B/vertex.
+// Reference-layout step (FEM_common.cu:82-166): the reference's arithmetic on the reference's own
+// arrays, restructured for this chip.  The reference scatters every face's weighted gradients to
+// its corners with 21 LDS atomics per face (6 float adds + 1 CAS-loop double add per corner,
+// :118-132); measured here that scatter was 3/4 of the kernel's time.  Instead each workgroup
+// builds the corner lists of its vertices in LDS -- count (1 integer atomic per owned corner),
+// scan, fill (1 more) -- parks the per-face gradients in LDS, and every vertex then SUMS its own
+// corners in ascending face-slot order: 6 integer atomics per face instead of 21 floating-point
+// ones, the same products ((float)(grad * weight), :122-127) added in float, the weight sum in
+// double, and -- unlike the reference -- a bit-reproducible result.
+// Further differences, none in the arithmetic: all loops are block-strided, so no thread leaves
+// before a barrier and a partition may hold more faces or vertices than the block has threads
+// (the reference returns early at :99-100 and :138-139); partitions are dealt to the XCDs in
+// consecutive runs.
+// LDS: off[size+1], cur[size] uint; ent[3*fpitch] uint; fg[6*fpitch] float  (8*size + 36*fpitch + 4 B).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ref_step_kernel(
     const double2 *__restrict__ fn_src, double2 *__restrict__ fn_dst, const uint *__restrict__ fv,
@@ -18,47 +25,75 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
     const double *__restrict__ vtxW, uint vw_pitch, const double *__restrict__ vertex_weights,
     uint vv_pitch, uint vws_pitch, uint vv_size, const float4 *__restrict__ grads, uint he_pitch,
     const uint *__restrict__ vertex_parts, const uint *__restrict__ block_face_count, double dt,
-    ModelD m) {
+    uint max_size, ModelD m) {
   extern __shared__ double s_mem[];
-  const uint p = blockIdx.x;
+  __shared__ uint s_tot[256], s_base[256];
+  // bijective XCD remap: workgroups are dealt round-robin over the 8 XCDs, so blocks b, b+8, ...
+  // (one XCD, one L2) take consecutive partitions -- neighbours in space, whose gathers of each
+  // other's state then hit that L2
+  const uint nblk = gridDim.x, q8 = nblk >> 3, r8 = nblk & 7u, xcd = blockIdx.x & 7u;
+  const uint p = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const uint base = vertex_parts[p];
   const uint size = vertex_parts[p + 1] - base;
-  double *s_wg = s_mem;
-  float *s_nv = reinterpret_cast<float *>(s_wg + size);
-  float *s_cv = s_nv + 3 * size;
+  const uint nfaces = block_face_count[p];
+  uint *s_off = reinterpret_cast<uint *>(s_mem);          // [max_size + 1]
+  uint *s_cur = s_off + max_size + 1;                     // [max_size]
+  uint *s_ent = s_cur + max_size;                         // [3 * fv_pitch]
+  float *s_fg = reinterpret_cast<float *>(s_ent + 3 * (size_t)fv_pitch);   // [6 * fv_pitch]
+  const uint tid = threadIdx.x;
 
-  for (uint i = threadIdx.x; i < size; i += blockDim.x) {
-    s_wg[i] = 0.0;
-    s_nv[3 * i] = s_nv[3 * i + 1] = s_nv[3 * i + 2] = 0.0f;
-    s_cv[3 * i] = s_cv[3 * i + 1] = s_cv[3 * i + 2] = 0.0f;
-  }
+  for (uint i = tid; i <= size; i += blockDim.x) { s_off[i] = 0; if (i < size) s_cur[i] = 0; }
   __syncthreads();
 
-  /* face gradients, scattered to the owned corners */
-  const uint nfaces = block_face_count[p];
+  /* face gradients (FEM_common.cu:99-116) parked in LDS; corners counted per owned vertex */
   const size_t fvb = (size_t)p * 3 * fv_pitch, fwb = (size_t)p * 3 * fvw_pitch, heb = (size_t)p * 2 * he_pitch;
-  for (uint t = threadIdx.x; t < nfaces; t += blockDim.x) {
+  for (uint t = tid; t < nfaces; t += blockDim.x) {
     const uint i0 = fv[fvb + t], i1 = fv[fvb + fv_pitch + t], i2 = fv[fvb + 2 * (size_t)fv_pitch + t];
     const double2 v1 = fn_src[i2], a = fn_src[i0], b = fn_src[i1];
+    const float4 g12 = grads[heb + t], g13 = grads[heb + he_pitch + t];
     const float d12x = (float)(a.x - v1.x), d12y = (float)(a.y - v1.y);
     const float d13x = (float)(b.x - v1.x), d13y = (float)(b.y - v1.y);
-    const float4 g12 = grads[heb + t], g13 = grads[heb + he_pitch + t];
-    const float nvx = g12.x * d12x + g13.x * d13x, nvy = g12.y * d12x + g13.y * d13x, nvz = g12.z * d12x + g13.z * d13x;
-    const float cvx = g12.x * d12y + g13.x * d13y, cvy = g12.y * d12y + g13.y * d13y, cvz = g12.z * d12y + g13.z * d13y;
+    float *fg = s_fg + 6 * (size_t)t;
+    fg[0] = g12.x * d12x + g13.x * d13x; fg[1] = g12.y * d12x + g13.y * d13x; fg[2] = g12.z * d12x + g13.z * d13x;
+    fg[3] = g12.x * d12y + g13.x * d13y; fg[4] = g12.y * d12y + g13.y * d13y; fg[5] = g12.z * d12y + g13.z * d13y;
     const uint idx[3] = {i0, i1, i2};
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const uint li = idx[j] - base;              // unsigned wrap makes "below base" large
-      if (li < size) {
-        const double weight = fv_weights[fwb + (size_t)j * fvw_pitch + t];
-        atomicAdd(&s_nv[3 * li], (float)(nvx * weight));
-        atomicAdd(&s_nv[3 * li + 1], (float)(nvy * weight));
-        atomicAdd(&s_nv[3 * li + 2], (float)(nvz * weight));
-        atomicAdd(&s_cv[3 * li], (float)(cvx * weight));
-        atomicAdd(&s_cv[3 * li + 1], (float)(cvy * weight));
-        atomicAdd(&s_cv[3 * li + 2], (float)(cvz * weight));
-        unsafeAtomicAdd(&s_wg[li], weight);
-      }
+      const uint li = idx[j] - base;                // unsigned wrap makes "below base" large
+      if (li < size) atomicAdd(&s_off[li + 1], 1u);
+    }
+  }
+  __syncthreads();
+
+  /* inclusive scan of s_off[0..size]: s_off[i] = first corner slot of vertex i */
+  {
+    const uint n = size + 1, chunk = (n + blockDim.x - 1) / blockDim.x;
+    const uint lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+    uint run = 0;
+    for (uint i = lo; i < hi; i++) { run += s_off[i]; s_off[i] = run; }
+    s_tot[tid] = run;
+    __syncthreads();
+    if (tid < 64) {
+      const uint t0 = s_tot[4 * tid], t1 = s_tot[4 * tid + 1], t2 = s_tot[4 * tid + 2], t3 = s_tot[4 * tid + 3];
+      const uint mine = t0 + t1 + t2 + t3;
+      uint incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const uint v = __shfl_up(incl, o); if ((int)tid >= o) incl += v; }
+      const uint excl = incl - mine;
+      s_base[4 * tid] = excl; s_base[4 * tid + 1] = excl + t0; s_base[4 * tid + 2] = excl + t0 + t1; s_base[4 * tid + 3] = excl + t0 + t1 + t2;
+    }
+    __syncthreads();
+    const uint add = s_base[tid];
+    for (uint i = lo; i < hi; i++) s_off[i] += add;
+  }
+  __syncthreads();
+
+  /* corner lists: entry = face slot << 2 | corner */
+  for (uint t = tid; t < nfaces; t += blockDim.x) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint li = fv[fvb + (size_t)j * fv_pitch + t] - base;
+      if (li < size) s_ent[s_off[li] + atomicAdd(&s_cur[li], 1u)] = (t << 2) | (uint)j;
     }
   }
   __syncthreads();
@@ -71,18 +106,49 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
     const double vW = vtxW[(size_t)p * vw_pitch + t];
     double lx = s.x * vW, ly = s.y * vW;
     const uint end = nbr[nb + t];
-    for (uint j = 0; j < end; j++) {
-      const uint nIdx = nbr[nb + (size_t)vv_pitch * (j + 1) + t];
-      const double hW = vertex_weights[wb + (size_t)vws_pitch * j + t];
-      const double2 f = fn_src[nIdx];
-      lx += f.x * hW; ly += f.y * hW;
+    // neighbours in groups of 8 with every load of a group in flight before the first use (padding
+    // slots hold index 0 / weight 0, main.cpp:261-287: loaded, not accumulated); same summation
+    // order as the reference's loop (FEM_common.cu:146-150)
+    // (the first group does not wait for `end`: its loads are clamped, its sums predicated)
+    for (uint j0 = 0; j0 < (vv_size ? max(end, 1u) : 0u); j0 += 8) {
+      uint nIdx[8];
+      double hW[8];
+      double2 f[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint j = min(j0 + u, vv_size - 1);
+        nIdx[u] = nbr[nb + (size_t)vv_pitch * (j + 1) + t];
+        hW[u] = vertex_weights[wb + (size_t)vws_pitch * j + t];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) f[u] = fn_src[nIdx[u]];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (j0 + u < end) { lx += f[u].x * hW[u]; ly += f[u].y * hW[u]; }
+    }
+    // this vertex's corners in ascending (face slot, corner) order: weighted gradient sums in float,
+    // weight sum in double (FEM_common.cu:118-132), then the normalised dot product (:153-158)
+    const uint eb = s_off[t], ee = s_off[t + 1];
+    for (uint i = eb + 1; i < ee; i++) {              // insertion sort, a handful of entries
+      const uint key = s_ent[i];
+      uint k = i;
+      while (k > eb && s_ent[k - 1] > key) { s_ent[k] = s_ent[k - 1]; k--; }
+      s_ent[k] = key;
+    }
+    float nvx = 0, nvy = 0, nvz = 0, cvx = 0, cvy = 0, cvz = 0;
+    double wg = 0;
+    for (uint i = eb; i < ee; i++) {
+      const uint ent = s_ent[i], slot = ent >> 2, j = ent & 3u;
+      const double weight = fv_weights[fwb + (size_t)j * fvw_pitch + slot];
+      const float *fg = s_fg + 6 * (size_t)slot;
+      nvx += (float)(fg[0] * weight); nvy += (float)(fg[1] * weight); nvz += (float)(fg[2] * weight);
+      cvx += (float)(fg[3] * weight); cvy += (float)(fg[4] * weight); cvz += (float)(fg[5] * weight);
+      wg += weight;
     }
     double dotP = 0;
-    const double wg = s_wg[t];
     if (wg > 0) {
       const float w = (float)wg;
-      dotP = (s_nv[3 * t] / w) * (s_cv[3 * t] / w) + (s_nv[3 * t + 1] / w) * (s_cv[3 * t + 1] / w) +
-             (s_nv[3 * t + 2] / w) * (s_cv[3 * t + 2] / w);
+      dotP = (nvx / w) * (cvx / w) + (nvy / w) * (cvy / w) + (nvz / w) * (cvz / w);
     }
     const double dauN = m.D * lx - m.alpha * s.x * ly - m.alpha * dotP + m.S * m.r * s.x * (m.nMax - s.x);
     const double dauC = ly + m.S * (s.x / (1 + s.x) - s.y);

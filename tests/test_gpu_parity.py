@@ -45,6 +45,19 @@ def test_reference_step_symbol(make, nparts):
     assert not np.array_equal(n_gpu, case.n0)
 
 
+def test_reference_step_is_bit_reproducible():
+    """the corner sums run in a fixed order (no floating-point atomics): same input, same bits"""
+    case = sphere_case(24, 9, seed=5)
+    outs = []
+    for _ in range(3):
+        lay, dev = _ref_device(case)
+        dev.set_state(case.n0, case.c0)
+        dev.run(7, case.dt, case.model)
+        outs.append(dev.get_state())
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1])
+
+
 def test_reference_layout_run_vs_packed_oracle():
     """fem_ref_device_run (20 steps) against the literal CPU model of stepKernel on the oracle's
     own packed arrays"""
