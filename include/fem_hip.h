@@ -58,8 +58,10 @@ void fem_free(void *p);      /* frees arrays returned through T** out-params */
  * Same name, argument order and meaning: device pointers laid out as
  * main.cpp:207-342 packs them, byte pitches as
  * cudaMallocPitch/cudaMalloc3D returned them, blocks = number of partitions.
- * `threads` and `smem_size` are accepted and ignored (the kernel picks its
- * own wave64 geometry).  Asynchronous on the default stream; constants =
+ * `threads` is accepted and ignored (the kernel picks its own wave64 geometry);
+ * `smem_size` = 32 B x the largest partition's vertex count, as the reference
+ * caller computes it (main.cpp:369), is read only for that count.
+ * Asynchronous on the default stream; constants =
  * fem_default_model().  Errors: fem_last_error() right after the call is this
  * call's status (a successful step() resets it to FEM_OK). */
 void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
@@ -70,9 +72,9 @@ void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_wei
           fem_uint blocks, fem_uint threads, double dt, fem_uint smem_size);
 
 /* The same launch with a status, explicit constants and stream (hipStream_t
- * as void*; NULL = default stream).  max_part_vertices = the largest
- * partition (sizes the LDS accumulators, main.cpp:369); 0 = derive it from
- * smem_size as the reference caller computed it (smem_size / 32). */
+ * as void*; NULL = default stream).  max_part_vertices = vertex count of the
+ * largest partition (with the face pitch it sizes the kernel's LDS work area:
+ * 8 B per vertex + 36 B per face slot, FEM_ERR_LIMIT beyond 158 KiB). */
 int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
              fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
              fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
