@@ -47,7 +47,7 @@ def test_reference_step_symbol(make, nparts):
 
 def test_reference_step_is_bit_reproducible():
     """the corner sums run in a fixed order (no floating-point atomics): same input, same bits"""
-    case = sphere_case(24, 9, seed=5)
+    case = sphere_case(24, 16, seed=5)
     outs = []
     for _ in range(3):
         lay, dev = _ref_device(case)
