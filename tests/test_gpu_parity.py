@@ -321,3 +321,41 @@ def test_irregular_mesh_small_tiles_and_sharded_plan():
         ns, cs = sp.get_state()
         own = slice(0, shard.n_own)
         assert rel_l2(ns[own], n3[l2g[own]]) <= TOL_F64 and rel_l2(cs[own], c3[l2g[own]]) <= TOL_F64
+
+
+def test_config3_full_size_properties():
+    """BASELINE config 3 size (nu = 1280, V = 16 384 002), fp32: the fused kernel and the
+    single-step kernel -- two layouts, two kernels -- agree after 12 steps; a constant state is a
+    fixed point; a second run reproduces the first bit for bit."""
+    pts, tri = fa.make_icosphere(1280, 0.1)
+    mesh = fa.Mesh(pts, tri)
+    del tri
+    part = mesh.partition(mesh.V // 620)
+    del mesh
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
+    model = fa.default_model()
+    n0, c0 = smooth_ic(om.points)
+    fused = fa.Plan(om, fa.PREC_F32, part=part, ksteps=4)
+    fused.set_state(n0, c0)
+    fused.run(12, dt, model)
+    a = fused.get_state()
+    fused.set_state(n0, c0)
+    fused.run(12, dt, model)
+    b = fused.get_state()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    m0 = fa.default_model()
+    m0.r = 0.0
+    n_const = np.full(om.V, 0.75)
+    fused.set_state(n_const, n_const / (1 + n_const))
+    fused.run(4, dt, m0)
+    n1, c1 = fused.get_state()
+    assert np.array_equal(n1, n_const.astype(np.float32).astype(np.float64)) and np.abs(c1 - n_const / (1 + n_const)).max() <= 1e-7
+    del fused
+    single = fa.Plan(om, fa.PREC_F32)
+    single.set_state(n0, c0)
+    single.run(12, dt, model)
+    s = single.get_state()
+    assert rel_l2(a[0], s[0]) <= 1e-6 and rel_l2(a[1], s[1]) <= 1e-6
+    assert np.isfinite(s[0]).all() and s[0].min() >= 0 and s[1].min() >= 0
