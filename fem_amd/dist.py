@@ -141,7 +141,7 @@ class ShardedRun:
         self.model = fa.default_model()
         self.dt = _time_step(om, self.model, dt_rule)
         self.precision = precision
-        self.krings = krings or int(os.environ.get("FEM_HALO_RINGS", "8"))
+        self.krings = krings or int(os.environ.get("FEM_HALO_RINGS", str(2 * ksteps if ksteps > 0 else 8)))   # two fused launches per exchange
         self.shard = fa.Shard(self.part, rank, world, self.krings)
         n0, c0 = fa.initial_condition(om.V, seed)                 # ordered numbering, identical on all ranks
         l2g = self.shard.loc2glob

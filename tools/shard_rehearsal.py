@@ -19,10 +19,10 @@ from fem_amd import dist as fdist  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "sphere16m"
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-krings = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+krings = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 400
 nu = {"sphere16m": 1280, "sphere4m": 640, "sphere1m": 320}[wl]
-fuse = int(os.environ.get("FEM_FUSE_STEPS", "4"))
+fuse = int(os.environ.get("FEM_FUSE_STEPS", "5"))
 
 
 class _Done:
@@ -39,7 +39,7 @@ fdist.exchange_halo = stub_exchange
 pts, tri = fa.make_icosphere(nu, 0.1)
 mesh = fa.Mesh(pts, tri)
 V = mesh.V
-run = fdist.ShardedRun(mesh, max(world, V // int(os.environ.get("FEM_TILE_N0", "620"))), rank, world, "f32", krings=krings,
+run = fdist.ShardedRun(mesh, max(world, V // int(os.environ.get("FEM_TILE_N0", {4: "620", 5: "530"}.get(fuse, "620")))), rank, world, "f32", krings=krings,
                        ksteps=fuse)
 del pts, tri, mesh
 stream = torch.cuda.current_stream()
