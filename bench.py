@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default=os.environ.get("FEM_BENCH_WORKLOAD", "sphere16m"), choices=sorted(WORKLOADS))
+    ap.add_argument("--mesh", default=None, help="a real .off/.ply surface instead of a synthetic workload (config 4 with real scans)")
+    ap.add_argument("--subdivide", type=int, default=0, help="rounds of 1-to-4 upsampling of --mesh")
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--fuse", type=int, default=None,
                     help="time steps fused per launch (0 = single-step sliced-ELL kernel); default FEM_FUSE_STEPS, "
@@ -102,14 +104,19 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    wl = WORKLOADS[args.workload]
+    wl = WORKLOADS[args.workload] if args.mesh is None else dict(nu=0, verts_per_part=256, scanned=True)
     if args.fuse is None:
         args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "4" if wl.get("scanned") else "5"))
     t_host = time.perf_counter()
     scanned = wl.get("scanned", False)
-    pts, tri = fa.make_scanned_like(wl["nu"], 0.1, seed=3) if scanned else fa.make_icosphere(wl["nu"], 0.1)
+    if args.mesh is not None:
+        pts, tri, _ = fa.read_mesh(args.mesh)
+        if args.subdivide > 0:
+            pts, tri = fa.subdivide(pts, tri, args.subdivide)
+    else:
+        pts, tri = fa.make_scanned_like(wl["nu"], 0.1, seed=3) if scanned else fa.make_icosphere(wl["nu"], 0.1)
     mesh = fa.Mesh(pts, tri)
-    V_total = mesh.V
+    V_total, n_faces = mesh.V, mesh.F
     dt_rule = "stable" if scanned else "reference"
     # fused tiles: partition size such that a partition + (fuse-1) rings fits the register tile
     tile_n0 = int(os.environ.get("FEM_TILE_N0", {4: "620", 5: "530", 6: "430"}.get(args.fuse, "620")))
@@ -170,8 +177,10 @@ def main():
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "%s: %s nu=%d, V=%d, F=%d, %d partitions, "
                                    "reaction-diffusion explicit Euler, seeded random IC"
-                                   % (args.workload, "scanned-like irregular surface (flipped/fanned/noisy geodesic sphere)"
-                                      if scanned else "class-I geodesic icosphere", wl["nu"], V_total, 2 * V_total - 4, nparts),
+                                   % (args.workload if args.mesh is None else os.path.basename(args.mesh) + " x4^%d" % args.subdivide,
+                                      "surface read from file" if args.mesh is not None else
+                                      "scanned-like irregular surface (flipped/fanned/noisy geodesic sphere)"
+                                      if scanned else "class-I geodesic icosphere", wl["nu"], V_total, n_faces, nparts),
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report,

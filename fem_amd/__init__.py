@@ -121,10 +121,19 @@ def make_strip(nx=11, ny=41, h=0.1):
     return _mesh_out(lib.fem_make_strip, C.c_int(nx), C.c_int(ny), C.c_double(h))
 
 
-def off_read(path):
+def ply_read(path):
+    return off_read(path, _fn=lib.fem_ply_read)
+
+
+def read_mesh(path):
+    """.off / .ply by extension"""
+    return ply_read(path) if path.lower().endswith(".ply") else off_read(path)
+
+
+def off_read(path, _fn=None):
     V, F = C.c_int(), C.c_int()
     pts, tri, rgb = f64p(), u32p(), u8p()
-    _check(lib.fem_off_read(path.encode(), C.byref(V), C.byref(F), C.byref(pts), C.byref(tri), C.byref(rgb)))
+    _check((_fn or lib.fem_off_read)(path.encode(), C.byref(V), C.byref(F), C.byref(pts), C.byref(tri), C.byref(rgb)))
     colors = _take(rgb, 3 * V.value, np.uint8).reshape(-1, 3) if rgb else None
     return (_take(pts, 3 * V.value, np.float64).reshape(-1, 3),
             _take(tri, 3 * F.value, np.uint32).reshape(-1, 3), colors)

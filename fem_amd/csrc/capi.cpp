@@ -52,6 +52,16 @@ int fem_off_read(const char *path, int *V, int *F, double **points, fem_uint **t
   return rc;
 }
 
+int fem_ply_read(const char *path, int *V, int *F, double **points, fem_uint **tri, unsigned char **rgb) {
+  if (!path || !V || !F || !points || !tri) return fail(FEM_ERR_INVALID, "fem_ply_read: null");
+  fem::SimpleTriMesh m;
+  int rc = fem::readPLY(path, m);
+  if (rc != FEM_OK) return fail(rc, path);
+  rc = exportMesh(m, V, F, points, tri);
+  if (rc == FEM_OK && rgb) *rgb = m.colors.empty() ? nullptr : dupArray(m.colors);
+  return rc;
+}
+
 int fem_off_write(const char *path, int V, int F, const double *points, const fem_uint *tri,
                   const unsigned char *rgb) {
   if (!path || V < 0 || F < 0 || (V && !points) || (F && !tri)) return fail(FEM_ERR_INVALID, "fem_off_write: bad argument");

@@ -94,6 +94,7 @@ int64_t edgeCut(const SimpleTriMesh &m, const int64_t *npart);
 
 // mesh IO + synthetic inputs
 int readOFF(const std::string &path, SimpleTriMesh &m);
+int readPLY(const std::string &path, SimpleTriMesh &m);
 int writeOFF(const std::string &path, const SimpleTriMesh &m);
 int makeIcosphere(int nu, double edge, SimpleTriMesh &m);
 int makeStrip(int nx, int ny, double h, SimpleTriMesh &m);

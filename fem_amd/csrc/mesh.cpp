@@ -376,6 +376,144 @@ int readOFF(const std::string &path, SimpleTriMesh &m) {
   return FEM_OK;
 }
 
+// Stanford PLY (what scans such as Lucy/bunny ship as; OpenMesh::IO::read_mesh takes it through the same
+// call, main.cpp:156-167): ascii and binary_little_endian 1.0, element vertex with x y z (any scalar
+// types; red green blue read when present, other properties skipped), element face with one list
+// property of vertex indices (other scalar properties skipped); polygons fan-triangulated.
+namespace {
+struct PlyProp { std::string name; int type = 0, listCount = -1; };   // type index into kPlySize; listCount >= 0: list
+const char *const kPlyNames[] = {"char", "uchar", "short", "ushort", "int", "uint", "float", "double",
+                                 "int8", "uint8", "int16", "uint16", "int32", "uint32", "float32", "float64"};
+const int kPlySize[] = {1, 1, 2, 2, 4, 4, 4, 8, 1, 1, 2, 2, 4, 4, 4, 8};
+int plyType(const std::string &t) {
+  for (int i = 0; i < 16; i++) if (t == kPlyNames[i]) return i;
+  return -1;
+}
+double plyBinary(const char *&p, int type) {
+  const int k = type % 8;
+  double v = 0;
+  switch (k) {
+    case 0: { int8_t x; memcpy(&x, p, 1); v = x; break; }
+    case 1: { uint8_t x; memcpy(&x, p, 1); v = x; break; }
+    case 2: { int16_t x; memcpy(&x, p, 2); v = x; break; }
+    case 3: { uint16_t x; memcpy(&x, p, 2); v = x; break; }
+    case 4: { int32_t x; memcpy(&x, p, 4); v = x; break; }
+    case 5: { uint32_t x; memcpy(&x, p, 4); v = x; break; }
+    case 6: { float x; memcpy(&x, p, 4); v = x; break; }
+    default: { double x; memcpy(&x, p, 8); v = x; break; }
+  }
+  p += kPlySize[type];
+  return v;
+}
+}  // namespace
+
+int readPLY(const std::string &path, SimpleTriMesh &m) {
+  FileBytes file;
+  if (!file.open(path)) return FEM_ERR_IO;
+  const char *p = file.data, *end = file.data + file.size;
+  auto line = [&](std::string &out) {
+    if (p >= end) return false;
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    const char *e = nl ? nl : end;
+    out.assign(p, e);
+    while (!out.empty() && (out.back() == '\r' || out.back() == ' ')) out.pop_back();
+    p = nl ? nl + 1 : end;
+    return true;
+  };
+  std::string l;
+  if (!line(l) || l != "ply") return FEM_ERR_IO;
+  bool ascii = false, haveFormat = false;
+  struct Elem { std::string name; long count = 0; std::vector<PlyProp> props; };
+  std::vector<Elem> elems;
+  for (;;) {
+    if (!line(l)) return FEM_ERR_IO;
+    char a[64] = "", b[64] = "", c[64] = "", d[64] = "", e[64] = "";
+    const int n = sscanf(l.c_str(), "%63s %63s %63s %63s %63s", a, b, c, d, e);
+    if (n < 1) continue;
+    const std::string key = a;
+    if (key == "end_header") break;
+    if (key == "comment" || key == "obj_info") continue;
+    if (key == "format") {
+      if (std::string(b) == "ascii") ascii = true;
+      else if (std::string(b) != "binary_little_endian") return FEM_ERR_IO;   // big-endian files: not supported
+      haveFormat = true;
+    } else if (key == "element" && n >= 3) {
+      Elem el; el.name = b; el.count = atol(c);
+      if (el.count < 0) return FEM_ERR_IO;
+      elems.push_back(el);
+    } else if (key == "property" && !elems.empty()) {
+      PlyProp pr;
+      if (std::string(b) == "list" && n >= 5) { pr.listCount = plyType(c); pr.type = plyType(d); pr.name = e; if (pr.listCount < 0) return FEM_ERR_IO; }
+      else if (n >= 3) { pr.type = plyType(b); pr.name = c; }
+      else return FEM_ERR_IO;
+      if (pr.type < 0) return FEM_ERR_IO;
+      elems.back().props.push_back(pr);
+    } else return FEM_ERR_IO;
+  }
+  if (!haveFormat) return FEM_ERR_IO;
+  m.clean();
+  Cursor cur{p, end};
+  long nv = -1;
+  std::vector<long> poly;
+  for (const Elem &el : elems) {
+    const bool isV = el.name == "vertex", isF = el.name == "face";
+    int ix = -1, iy = -1, iz = -1, ir = -1, ig = -1, ib = -1, il = -1;
+    for (size_t k = 0; k < el.props.size(); k++) {
+      const PlyProp &pr = el.props[k];
+      if (isV && pr.listCount >= 0) return FEM_ERR_IO;
+      if (pr.name == "x") ix = (int)k; else if (pr.name == "y") iy = (int)k; else if (pr.name == "z") iz = (int)k;
+      else if (pr.name == "red") ir = (int)k; else if (pr.name == "green") ig = (int)k; else if (pr.name == "blue") ib = (int)k;
+      if (isF && pr.listCount >= 0 && il < 0) il = (int)k;
+    }
+    if (isV) {
+      if (ix < 0 || iy < 0 || iz < 0 || el.count > 0xfffffff0l) return FEM_ERR_IO;
+      nv = el.count;
+      m.points.resize(3 * (size_t)nv);
+      const bool col = ir >= 0 && ig >= 0 && ib >= 0;
+      if (col) m.colors.resize(3 * (size_t)nv);
+    }
+    if (isF && (il < 0 || nv < 0)) return FEM_ERR_IO;
+    if (isF) m.faces.reserve(3 * (size_t)el.count);
+    for (long i = 0; i < el.count; i++)
+      for (size_t k = 0; k < el.props.size(); k++) {
+        const PlyProp &pr = el.props[k];
+        long cnt = 1;
+        if (pr.listCount >= 0) {
+          double c;
+          if (ascii) { if (!cur.num(c)) return FEM_ERR_IO; }
+          else { if (cur.p + kPlySize[pr.listCount] > end) return FEM_ERR_IO; c = plyBinary(cur.p, pr.listCount); }
+          cnt = (long)c;
+          if (cnt < 0 || cnt > 1000000) return FEM_ERR_IO;
+          if (isF && (int)k == il) poly.resize((size_t)cnt);
+        }
+        for (long q = 0; q < cnt; q++) {
+          double v;
+          if (ascii) { if (!cur.num(v)) return FEM_ERR_IO; }
+          else { if (cur.p + kPlySize[pr.type] > end) return FEM_ERR_IO; v = plyBinary(cur.p, pr.type); }
+          if (isV) {
+            const int kk = (int)k;
+            if (kk == ix) m.points[3 * (size_t)i] = v; else if (kk == iy) m.points[3 * (size_t)i + 1] = v;
+            else if (kk == iz) m.points[3 * (size_t)i + 2] = v;
+            else if (!m.colors.empty() && (kk == ir || kk == ig || kk == ib)) {
+              const double s = pr.type % 8 >= 6 ? v * 255.0 : v;          // float colours are in [0, 1]
+              m.colors[3 * (size_t)i + (kk == ir ? 0 : (kk == ig ? 1 : 2))] = (unsigned char)std::min(255.0, std::max(0.0, std::floor(s + 0.5)));
+            }
+          } else if (isF && (int)k == il) {
+            if (v < 0 || v >= (double)nv) return FEM_ERR_IO;
+            poly[(size_t)q] = (long)v;
+          }
+        }
+        if (isF && (int)k == il) {
+          if (cnt < 3) return FEM_ERR_IO;
+          for (long q = 1; q + 1 < cnt; q++) m.add_face((uint)poly[0], (uint)poly[(size_t)q], (uint)poly[(size_t)q + 1]);
+        }
+      }
+  }
+  if (nv < 0) return FEM_ERR_IO;
+  m.H = 0;
+  return FEM_OK;
+}
+
 // COFF / OFF writer (the shape of ResultantPattern.off).  Records are formatted by host threads
 // into per-chunk buffers and written in order.
 int writeOFF(const std::string &path, const SimpleTriMesh &m) {

@@ -92,6 +92,11 @@ int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_
  * malloc'ed; release with fem_free. */
 int fem_off_read(const char *path, int *V, int *F, double **points, fem_uint **tri,
                  unsigned char **rgb);
+/* Stanford PLY load (the format scans ship in; the reference reaches it through the same
+ * OpenMesh::IO::read_mesh call): ascii and binary_little_endian, x y z of any scalar type, optional
+ * red/green/blue, polygons fan-triangulated; same outputs as fem_off_read. */
+int fem_ply_read(const char *path, int *V, int *F, double **points, fem_uint **tri,
+                 unsigned char **rgb);
 /* COFF writer ("visualisation output" without GL; file shape of
  * ResultantPattern.off:1-4).  rgb may be NULL (plain OFF). */
 int fem_off_write(const char *path, int V, int F, const double *points, const fem_uint *tri,

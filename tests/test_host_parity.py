@@ -344,3 +344,48 @@ def test_subdivide_upsampler():
     bad[0] = bad[0][::-1]
     with pytest.raises(fa.FemError):
         fa.subdivide(ps, bad, 1)
+
+
+def test_ply_reader(tmp_path):
+    """Stanford PLY, ascii and binary little-endian: mixed property types, colours, extra
+    properties skipped, a quad fan-triangulated; malformed files are errors"""
+    pts, tri = fa.make_icosphere(4, 0.1)
+    V, F = len(pts), len(tri)
+    rgb = (np.arange(3 * V) % 256).astype(np.uint8).reshape(-1, 3)
+    # ascii: double coords, a skipped property, uchar colours, face with a leading scalar property
+    a = str(tmp_path / "a.ply")
+    with open(a, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment made by test\nelement vertex %d\nproperty double x\nproperty double y\n"
+                "property double z\nproperty float confidence\nproperty uchar red\nproperty uchar green\nproperty uchar blue\n"
+                "element face %d\nproperty uchar flags\nproperty list uchar int vertex_indices\nend_header\n" % (V, F - 1))
+        for i in range(V):
+            f.write("%r %r %r 0.5 %d %d %d\n" % (float(pts[i, 0]), float(pts[i, 1]), float(pts[i, 2]), *rgb[i]))
+        q = [int(x) for x in tri[0]] + [next(int(x) for x in tri[1] if int(x) not in tri[0])]
+        f.write("7 4 %d %d %d %d\n" % tuple(q))
+        for t in tri[2:]:
+            f.write("0 3 %d %d %d\n" % tuple(t))
+    p2, t2, c2 = fa.ply_read(a)
+    assert np.array_equal(p2, pts) and np.array_equal(c2, rgb)
+    assert np.array_equal(t2[:2], [[q[0], q[1], q[2]], [q[0], q[2], q[3]]]) and np.array_equal(t2[2:], tri[2:])
+    # binary little-endian: float coords, ushort extra property, uint8 list count, uint indices
+    b = str(tmp_path / "b.ply")
+    vrec = np.zeros(V, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("q", "<u2")])
+    vrec["x"], vrec["y"], vrec["z"], vrec["q"] = pts[:, 0], pts[:, 1], pts[:, 2], 7
+    frec = np.zeros(F, dtype=[("n", "u1"), ("a", "<u4"), ("b", "<u4"), ("c", "<u4")])
+    frec["n"], frec["a"], frec["b"], frec["c"] = 3, tri[:, 0], tri[:, 1], tri[:, 2]
+    with open(b, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                 "property ushort q\nelement face %d\nproperty list uint8 uint vertex_index\nend_header\n" % (V, F)).encode())
+        f.write(vrec.tobytes())
+        f.write(frec.tobytes())
+    p3, t3, c3 = fa.read_mesh(b)
+    assert c3 is None and np.array_equal(t3, tri) and np.array_equal(p3, pts.astype(np.float32).astype(np.float64))
+    fa.Mesh(p3, t3)                                            # a valid manifold mesh
+    # truncated body, big-endian, bad index, not a ply
+    open(str(tmp_path / "c.ply"), "wb").write(open(b, "rb").read()[:-5])
+    open(str(tmp_path / "d.ply"), "wb").write(open(b, "rb").read().replace(b"binary_little_endian", b"binary_big_endian"))
+    open(str(tmp_path / "e.ply"), "w").write(open(a).read().replace("\n0 3 ", "\n0 3 99999 ", 1))
+    open(str(tmp_path / "f.ply"), "w").write("OFF\n0 0 0\n")
+    for name in "cdef":
+        with pytest.raises(fa.FemError):
+            fa.ply_read(str(tmp_path / (name + ".ply")))
