@@ -174,7 +174,7 @@ def main():
             "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic",
+            "dtype": args.precision, "data": "synthetic" if args.mesh is None else "file " + os.path.basename(args.mesh),
             "config": {"workload": "%s: %s nu=%d, V=%d, F=%d, %d partitions, "
                                    "reaction-diffusion explicit Euler, seeded random IC"
                                    % (args.workload if args.mesh is None else os.path.basename(args.mesh) + " x4^%d" % args.subdivide,
