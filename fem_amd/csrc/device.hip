@@ -178,7 +178,11 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   // One variant for regular and irregular meshes: the build with the wide-row loop measured 4 %
   // FASTER on the regular 16M sphere than the one without it (same-box A/B, 213.5 vs 204.3 G
   // DOF-it/s), so the X = false instantiation is not dispatched.
-  static const int pro = getenv("FEM_TILE_PROLOGUE") ? atoi(getenv("FEM_TILE_PROLOGUE")) : 3;   // tuning knob; 3 measured best
+  // Read-once streams go around the caches (nontemporal) only when they cannot live in the 256 MiB
+  // Infinity Cache anyway: at 1M vertices (operator 230 MB) plain loads keep the operator cached
+  // between launches (247 vs 210 G DOF-it/s), from 4M on the nontemporal ones win (230 vs 223 G).
+  static const int proEnv = getenv("FEM_TILE_PROLOGUE") ? atoi(getenv("FEM_TILE_PROLOGUE")) : -1;   // tuning knob
+  const int pro = proEnv >= 0 ? proEnv : (p->tile_bytes > (256ull << 20) ? 3 : 1);
   auto kern = pro == 3 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 3> : pro == 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 2>
                        : (pro == 1 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, true, 0>);
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
@@ -693,7 +697,8 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
                        1.0 / (1.0 + p->base_n)};
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
-    static const bool nt = !(getenv("FEM_SELL_NT") && atoi(getenv("FEM_SELL_NT")) == 0);
+    static const int ntEnv = getenv("FEM_SELL_NT") ? atoi(getenv("FEM_SELL_NT")) : -1;
+    const bool nt = ntEnv >= 0 ? ntEnv != 0 : fem_plan_operator_bytes(p) > (256ull << 20);   // see launchTile
     if (p->precision == FEM_PREC_F32)
       hipLaunchKernelGGL((nt ? sell_step_kernel<float, true> : sell_step_kernel<float, false>), dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
