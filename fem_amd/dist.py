@@ -156,6 +156,7 @@ class ShardedRun:
         self.pending, self.pending_exchange = None, False          # exchange in flight (overlapped schedule)
         tc = getattr(self.stepper, "tile_classes", None)
         self.classes = tc() if (tc is not None and os.environ.get("FEM_OVERLAP", "1") != "0") else None
+        self.force_split = os.environ.get("FEM_OVERLAP", "1") == "split"   # tests: always take the not-yet-arrived path
         # one exchange up front (re-sends the ghosts' own initial values): brings up the RCCL
         # communicator and its buffers outside any timed region
         import torch.distributed as dist
@@ -191,18 +192,26 @@ class ShardedRun:
         while done < nsteps:
             s = min(self.ksteps, self.budget, nsteps - done)
             first, last = self.pending_exchange, self.budget == s
+            merged = False
             if first:
-                st.launch(0, nI, s, dt, model, stream)
-                self._wait_exchange()
+                # the exchange has had the previous group's interior launch to finish: if it has,
+                # this group is ONE launch (no short boundary launch with its tail); if not, the
+                # interior tiles go first and the wait comes after them
+                if not self.force_split and (self.pending is None or self.pending.is_completed()):
+                    self._wait_exchange()
+                    merged = True
+                else:
+                    st.launch(0, nI, s, dt, model, stream)
+                    self._wait_exchange()
             if last:
                 st.launch(nI, nB, s, dt, model, stream)
                 self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=True)
                 self.pending_exchange = True
-                if not first:
+                if not first or merged:
                     st.launch(0, nI, s, dt, model, stream)
                 self.budget = self.krings
             else:
-                if first:
+                if first and not merged:
                     st.launch(nI, nB + nG, s, dt, model, stream)
                 else:
                     st.launch(0, nI + nB + nG, s, dt, model, stream)
