@@ -9,6 +9,7 @@
 
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -166,6 +167,17 @@ struct Shard {
 };
 int buildShard(const SimpleTriMesh &m, int n, const uint *node_parts, int rank, int nranks, int krings,
                Shard &out);
+
+// host worker threads for the embarrassingly parallel loops (FEM_HOST_THREADS, default min(16, cores))
+int hostThreads();
+// fn(begin, end) over [0, n) in contiguous chunks, one per thread; serial below `grain` items
+template <typename Fn> void parallelFor(size_t n, size_t grain, Fn fn) {
+  const int T = n >= grain ? hostThreads() : 1;
+  if (T <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < T; t++) th.emplace_back([=]() { fn(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); });
+  for (auto &x : th) x.join();
+}
 
 // records status + message for fem_last_error()/fem_error_detail(); returns status
 int fail(int status, const char *what);

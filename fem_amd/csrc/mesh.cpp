@@ -216,7 +216,7 @@ struct Cursor {
   }
 };
 
-static int hostThreads() {
+int hostThreads() {
   const char *e = getenv("FEM_HOST_THREADS");
   int n = e ? atoi(e) : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   return std::max(1, std::min(n, 64));

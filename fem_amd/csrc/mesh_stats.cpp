@@ -3,6 +3,8 @@
 // Follows reference src/mesh_function.cpp:27-67 (initMeshStats), :70-160
 // (angles/cot), :162-216 (areas), :219-271 (Laplacian weights), :310-350 (max
 // edge), :351-397 (gradient vectors) and src/mesh_function.h:6-110 (operators).
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 
 #include "fem_host.hpp"
@@ -34,8 +36,11 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
   s.gradVec12.assign(3 * (size_t)F, 0.0); s.gradVec13.assign(3 * (size_t)F, 0.0);
 
   // per face: the three corner angles (angle at the to-vertex of each of its
-  // half-edges), cotangents, area, hat-function gradients
-  for (int f = 0; f < F; f++) {
+  // half-edges), cotangents, area, hat-function gradients.  Faces write only their own slots, so
+  // the loop runs on the host threads; the scatters below keep their serial order (bit-identical
+  // sums whatever the thread count).
+  parallelFor((size_t)F, 100000, [&](size_t fb, size_t fe) {
+  for (int f = (int)fb; f < (int)fe; f++) {
     const uint ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
     const Vec3<G> pa(P + 3 * ia), pb(P + 3 * ib), pc(P + 3 * ic);
     const Vec3<G> corner[3] = {pa, pb, pc};
@@ -51,7 +56,6 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
     Vec3<G> v21 = pc - pa, v23 = pb - pa;
     double area = v21.cross(v23).norm() / 2;
     s.meshArea[f] = area;
-    s.areaPerVtx[ic] += area / 3; s.areaPerVtx[ia] += area / 3; s.areaPerVtx[ib] += area / 3;
 
     // face normal from the double points, narrowed, re-normalised in G
     double e1[3], e2[3];
@@ -67,23 +71,36 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
     s.gradVec12[3 * f] = g12.x; s.gradVec12[3 * f + 1] = g12.y; s.gradVec12[3 * f + 2] = g12.z;
     s.gradVec13[3 * f] = g13.x; s.gradVec13[3 * f + 1] = g13.y; s.gradVec13[3 * f + 2] = g13.z;
   }
+  });
+  for (int f = 0; f < F; f++) {                         // lumped mass, in face order (mesh_function.cpp:205-209)
+    const double a3 = s.meshArea[f] / 3;
+    s.areaPerVtx[m.faces[3 * f + 2]] += a3; s.areaPerVtx[m.faces[3 * f]] += a3; s.areaPerVtx[m.faces[3 * f + 1]] += a3;
+  }
 
   // cot-Laplacian rows scaled by the inverse lumped mass
-  for (int h = 0; h < H; h++) {
-    const int ho = m.opp[h];
-    double wg = 0;
-    if (h < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(h)];
-    if (ho < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(ho)];
-    const uint v1 = m.he_from[h];
-    s.wHej[h] = wg / (2 * s.areaPerVtx[v1]);
-    s.wVtx[v1] -= s.wHej[h];
-  }
+  parallelFor((size_t)H, 300000, [&](size_t hb, size_t he) {
+    for (int h = (int)hb; h < (int)he; h++) {
+      const int ho = m.opp[h];
+      double wg = 0;
+      if (h < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(h)];
+      if (ho < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(ho)];
+      s.wHej[h] = wg / (2 * s.areaPerVtx[m.he_from[h]]);
+    }
+  });
+  for (int h = 0; h < H; h++) s.wVtx[m.he_from[h]] -= s.wHej[h];     // in half-edge order
 
+  std::vector<double> part((size_t)hostThreads() + 1, 0.0);
+  std::atomic<int> slot(0);
+  parallelFor((size_t)H, 300000, [&](size_t hb, size_t he) {
+    double mx = 0;
+    for (int h = (int)hb; h < (int)he; h++) {
+      double len = (Vec3<G>(P + 3 * m.he_from[h]) - Vec3<G>(P + 3 * m.he_to[h])).norm();
+      if (len > mx) mx = len;
+    }
+    part[(size_t)slot.fetch_add(1)] = mx;
+  });
   double mx = 0;
-  for (int h = 0; h < H; h++) {
-    double len = (Vec3<G>(P + 3 * m.he_from[h]) - Vec3<G>(P + 3 * m.he_to[h])).norm();
-    if (len > mx) mx = len;
-  }
+  for (double v : part) mx = std::max(mx, v);
   s.maxEdgeLen = mx;
 }
 

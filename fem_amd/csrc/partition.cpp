@@ -7,6 +7,7 @@
 // keep the reference's exact rules.
 #include <algorithm>
 #include <cstring>
+#include <thread>
 
 #include "fem_host.hpp"
 
@@ -24,7 +25,9 @@ struct Rcb {
   const double *pts;
   int64_t *npart;
   std::vector<uint32_t> ids;
-  void run(size_t b, size_t e, int p0, int np) {
+  // the two halves of a split touch disjoint ranges of ids[] and npart[]: the top levels of the
+  // recursion run their left halves on their own threads (same result whatever the thread count)
+  void run(size_t b, size_t e, int p0, int np, int depth = 0) {
     while (np > 1) {
       double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
       for (size_t i = b; i < e; i++)
@@ -42,7 +45,13 @@ struct Rcb {
         const double a = P[3 * (size_t)x + ax], c = P[3 * (size_t)y + ax];
         return a < c || (a == c && x < y);
       });
-      run(b, mid, p0, nl);            // recurse left, iterate right
+      if (depth < 4 && e - b > 400000 && hostThreads() > 1) {
+        std::thread left([=]() { run(b, mid, p0, nl, depth + 1); });
+        run(mid, e, p0 + nl, np - nl, depth + 1);
+        left.join();
+        return;
+      }
+      run(b, mid, p0, nl, depth + 1);            // recurse left, iterate right
       b = mid; p0 += nl; np -= nl;
     }
     for (size_t i = b; i < e; i++) npart[ids[i]] = p0;
