@@ -2,6 +2,7 @@
 // Stands in for what the reference gets from OpenMesh (src/common.h:41-52,
 // src/main.cpp:156-167); conventions in fem_host.hpp / DESIGN.md.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -39,29 +40,36 @@ int SimpleTriMesh::update_topology() {
     int pos = ptr[a + 1]++;
     to[pos] = b; he[pos] = h;
   }
-  for (int v = 0; v < V; v++) {                       // insertion sort, rows are tiny
-    for (int i = ptr[v] + 1; i < ptr[v + 1]; i++) {
-      uint t = to[i]; int32_t hh = he[i]; int j = i - 1;
-      while (j >= ptr[v] && to[j] > t) { to[j + 1] = to[j]; he[j + 1] = he[j]; j--; }
-      to[j + 1] = t; he[j + 1] = hh;
+  std::atomic<int> nonManifold(0);
+  parallelFor((size_t)V, 200000, [&](size_t vb, size_t ve) {     // rows are independent
+    for (int v = (int)vb; v < (int)ve; v++) {                   // insertion sort, rows are tiny
+      for (int i = ptr[v] + 1; i < ptr[v + 1]; i++) {
+        uint t = to[i]; int32_t hh = he[i]; int j = i - 1;
+        while (j >= ptr[v] && to[j] > t) { to[j + 1] = to[j]; he[j + 1] = he[j]; j--; }
+        to[j + 1] = t; he[j + 1] = hh;
+      }
+      for (int i = ptr[v] + 1; i < ptr[v + 1]; i++)
+        if (to[i] == to[i - 1]) nonManifold = 1;
     }
-    for (int i = ptr[v] + 1; i < ptr[v + 1]; i++)
-      if (to[i] == to[i - 1]) return FEM_ERR_NONMANIFOLD;
-  }
+  });
+  if (nonManifold) return FEM_ERR_NONMANIFOLD;
 
   opp.assign(H3, -1);
   he_from.resize(H3); he_to.resize(H3);
+  parallelFor((size_t)H3, 300000, [&](size_t hb, size_t hend) {  // opposite = the entry (b -> a) of row b
+    for (int h = (int)hb; h < (int)hend; h++) {
+      int f = h / 3, k = h % 3;
+      uint a = faces[h], b = faces[3 * f + (k + 1) % 3];
+      he_from[h] = a; he_to[h] = b;
+      const uint *lo = to.data() + ptr[b], *hi = to.data() + ptr[b + 1];
+      const uint *it = std::lower_bound(lo, hi, a);
+      if (it != hi && *it == a) opp[h] = he[it - to.data()];
+    }
+  });
   std::vector<int32_t> extra(V + 1, 0);               // boundary half-edges leaving each vertex
   int B = 0;
-  for (int h = 0; h < H3; h++) {
-    int f = h / 3, k = h % 3;
-    uint a = faces[h], b = faces[3 * f + (k + 1) % 3];
-    he_from[h] = a; he_to[h] = b;
-    const uint *lo = to.data() + ptr[b], *hi = to.data() + ptr[b + 1];
-    const uint *it = std::lower_bound(lo, hi, a);
-    if (it != hi && *it == a) opp[h] = he[it - to.data()];
-    else { extra[b]++; B++; }
-  }
+  for (int h = 0; h < H3; h++)
+    if (opp[h] < 0) { extra[he_to[h]]++; B++; }
   H = H3 + B;
   opp.resize(H); he_from.resize(H); he_to.resize(H);
   for (int h = 0, b = 0; h < H3; h++)
