@@ -269,11 +269,11 @@ int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_
       vw_pitchInBytes % sizeof(double) || vv_pitchInBytes % sizeof(fem_uint) ||
       vws_pitchInBytes % sizeof(double) || he_pitchInBytes % sizeof(fem_float4))
     return fail(FEM_ERR_INVALID, "fem_step: pitch not a multiple of the element size");
-  // corner lists + per-face gradients in LDS (ref_step_kernel): 8 B per vertex + 36 B per face slot
+  // corner lists + per-face gradients in LDS (ref_step_kernel): 4 (1 + vv_size) B per vertex + 24 B per face slot
   const size_t fpitch = fv_pitchInBytes / sizeof(fem_uint);
-  const size_t lds = (size_t)max_part_vertices * 8 + fpitch * 36 + 8;
-  if (max_part_vertices == 0 || lds > 160 * 1024 - 2048)
-    return fail(FEM_ERR_LIMIT, "fem_step: partition too large for the LDS work area (8 B per vertex + 36 B per face slot <= 158 KiB)");
+  const size_t lds = (size_t)max_part_vertices * 4 * (1 + (size_t)vv_size) + fpitch * 24 + 16;
+  if (max_part_vertices == 0 || lds > 160 * 1024)
+    return fail(FEM_ERR_LIMIT, "fem_step: partition too large for the LDS work area (4 (1 + vv_size) B per vertex + 24 B per face slot <= 160 KiB)");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   ModelD m = {model->nMax, model->D, model->r, model->alpha, model->S};

@@ -8,16 +8,16 @@
 // arrays, restructured for this chip.  The reference scatters every face's weighted gradients to
 // its corners with 21 LDS atomics per face (6 float adds + 1 CAS-loop double add per corner,
 // :118-132); measured here that scatter was 3/4 of the kernel's time.  Instead each workgroup
-// builds the corner lists of its vertices in LDS -- count (1 integer atomic per owned corner),
-// scan, fill (1 more) -- parks the per-face gradients in LDS, and every vertex then SUMS its own
-// corners in ascending face-slot order: 6 integer atomics per face instead of 21 floating-point
-// ones, the same products ((float)(grad * weight), :122-127) added in float, the weight sum in
+// builds the corner lists of its vertices in LDS (one integer atomic per owned corner; a vertex has
+// at most vv_size incident faces, so the lists have fixed slots), parks the per-face gradients in
+// LDS, and every vertex then SUMS its own corners in ascending face-slot order: 3 integer atomics
+// per face instead of 21 floating-point ones, the same products ((float)(grad * weight), :122-127) added in float, the weight sum in
 // double, and -- unlike the reference -- a bit-reproducible result.
 // Further differences, none in the arithmetic: all loops are block-strided, so no thread leaves
 // before a barrier and a partition may hold more faces or vertices than the block has threads
 // (the reference returns early at :99-100 and :138-139); partitions are dealt to the XCDs in
 // consecutive runs.
-// LDS: off[size+1], cur[size] uint; ent[3*fpitch] uint; fg[6*fpitch] float  (8*size + 36*fpitch + 4 B).
+// LDS: cur[size], ent[size*vv_size] uint; fg[6*fpitch] float  (4*size*(1 + vv_size) + 24*fpitch B).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ref_step_kernel(
     const double2 *__restrict__ fn_src, double2 *__restrict__ fn_dst, const uint *__restrict__ fv,
@@ -27,7 +27,6 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
     const uint *__restrict__ vertex_parts, const uint *__restrict__ block_face_count, double dt,
     uint max_size, ModelD m) {
   extern __shared__ double s_mem[];
-  __shared__ uint s_tot[256], s_base[256];
   // bijective XCD remap: workgroups are dealt round-robin over the 8 XCDs, so blocks b, b+8, ...
   // (one XCD, one L2) take consecutive partitions -- neighbours in space, whose gathers of each
   // other's state then hit that L2
@@ -36,16 +35,17 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
   const uint base = vertex_parts[p];
   const uint size = vertex_parts[p + 1] - base;
   const uint nfaces = block_face_count[p];
-  uint *s_off = reinterpret_cast<uint *>(s_mem);          // [max_size + 1]
-  uint *s_cur = s_off + max_size + 1;                     // [max_size]
-  uint *s_ent = s_cur + max_size;                         // [3 * fv_pitch]
-  float *s_fg = reinterpret_cast<float *>(s_ent + 3 * (size_t)fv_pitch);   // [6 * fv_pitch]
+  // A vertex has at most vv_size (= the largest valence, main.cpp:261-287) incident faces, so its
+  // corner list gets a fixed slot range: no counting pass, no scan.
+  uint *s_cur = reinterpret_cast<uint *>(s_mem);          // [max_size]            corners filled so far
+  uint *s_ent = s_cur + max_size;                         // [max_size * vv_size]  face slot << 2 | corner
+  float *s_fg = reinterpret_cast<float *>(s_ent + (size_t)max_size * vv_size);   // [6 * fv_pitch]
   const uint tid = threadIdx.x;
 
-  for (uint i = tid; i <= size; i += blockDim.x) { s_off[i] = 0; if (i < size) s_cur[i] = 0; }
+  for (uint i = tid; i < size; i += blockDim.x) s_cur[i] = 0;
   __syncthreads();
 
-  /* face gradients (FEM_common.cu:99-116) parked in LDS; corners counted per owned vertex */
+  /* face gradients (FEM_common.cu:99-116) parked in LDS; each owned corner appended to its vertex's list */
   const size_t fvb = (size_t)p * 3 * fv_pitch, fwb = (size_t)p * 3 * fvw_pitch, heb = (size_t)p * 2 * he_pitch;
   for (uint t = tid; t < nfaces; t += blockDim.x) {
     const uint i0 = fv[fvb + t], i1 = fv[fvb + fv_pitch + t], i2 = fv[fvb + 2 * (size_t)fv_pitch + t];
@@ -60,40 +60,10 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const uint li = idx[j] - base;                // unsigned wrap makes "below base" large
-      if (li < size) atomicAdd(&s_off[li + 1], 1u);
-    }
-  }
-  __syncthreads();
-
-  /* inclusive scan of s_off[0..size]: s_off[i] = first corner slot of vertex i */
-  {
-    const uint n = size + 1, chunk = (n + blockDim.x - 1) / blockDim.x;
-    const uint lo = min(tid * chunk, n), hi = min(lo + chunk, n);
-    uint run = 0;
-    for (uint i = lo; i < hi; i++) { run += s_off[i]; s_off[i] = run; }
-    s_tot[tid] = run;
-    __syncthreads();
-    if (tid < 64) {
-      const uint t0 = s_tot[4 * tid], t1 = s_tot[4 * tid + 1], t2 = s_tot[4 * tid + 2], t3 = s_tot[4 * tid + 3];
-      const uint mine = t0 + t1 + t2 + t3;
-      uint incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const uint v = __shfl_up(incl, o); if ((int)tid >= o) incl += v; }
-      const uint excl = incl - mine;
-      s_base[4 * tid] = excl; s_base[4 * tid + 1] = excl + t0; s_base[4 * tid + 2] = excl + t0 + t1; s_base[4 * tid + 3] = excl + t0 + t1 + t2;
-    }
-    __syncthreads();
-    const uint add = s_base[tid];
-    for (uint i = lo; i < hi; i++) s_off[i] += add;
-  }
-  __syncthreads();
-
-  /* corner lists: entry = face slot << 2 | corner */
-  for (uint t = tid; t < nfaces; t += blockDim.x) {
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const uint li = fv[fvb + (size_t)j * fv_pitch + t] - base;
-      if (li < size) s_ent[s_off[li] + atomicAdd(&s_cur[li], 1u)] = (t << 2) | (uint)j;
+      if (li < size) {
+        const uint pos = atomicAdd(&s_cur[li], 1u);
+        if (pos < vv_size) s_ent[(size_t)li * vv_size + pos] = (t << 2) | (uint)j;
+      }
     }
   }
   __syncthreads();
@@ -128,7 +98,7 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
     }
     // this vertex's corners in ascending (face slot, corner) order: weighted gradient sums in float,
     // weight sum in double (FEM_common.cu:118-132), then the normalised dot product (:153-158)
-    const uint eb = s_off[t], ee = s_off[t + 1];
+    const uint eb = t * vv_size, ee = eb + min(s_cur[t], vv_size);
     for (uint i = eb + 1; i < ee; i++) {              // insertion sort, a handful of entries
       const uint key = s_ent[i];
       uint k = i;

@@ -73,8 +73,9 @@ void step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_wei
 
 /* The same launch with a status, explicit constants and stream (hipStream_t
  * as void*; NULL = default stream).  max_part_vertices = vertex count of the
- * largest partition (with the face pitch it sizes the kernel's LDS work area:
- * 8 B per vertex + 36 B per face slot, FEM_ERR_LIMIT beyond 158 KiB). */
+ * largest partition (with vv_size and the face pitch it sizes the kernel's LDS
+ * work area: 4 (1 + vv_size) B per vertex + 24 B per face slot, FEM_ERR_LIMIT
+ * beyond 160 KiB). */
 int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
              fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
              fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,
