@@ -326,7 +326,7 @@ def test_irregular_mesh_small_tiles_and_sharded_plan():
 def test_config3_full_size_properties():
     """BASELINE config 3 size (nu = 1280, V = 16 384 002), fp32: the fused kernel and the
     single-step kernel -- two layouts, two kernels -- agree after 12 steps; a constant state is a
-    fixed point; a second run reproduces the first bit for bit."""
+    fixed point; a second run reproduces the first bit for bit; the fp64 plan is within 1e-5."""
     pts, tri = fa.make_icosphere(1280, 0.1)
     mesh = fa.Mesh(pts, tri)
     del tri
@@ -359,3 +359,10 @@ def test_config3_full_size_properties():
     s = single.get_state()
     assert rel_l2(a[0], s[0]) <= 1e-6 and rel_l2(a[1], s[1]) <= 1e-6
     assert np.isfinite(s[0]).all() and s[0].min() >= 0 and s[1].min() >= 0
+    del single
+    # and both are within the stated fp32 tolerance of the all-fp64 plan at this size
+    p64 = fa.Plan(om, fa.PREC_F64)
+    p64.set_state(n0.astype(np.float32), c0.astype(np.float32))
+    p64.run(12, dt, model)
+    d = p64.get_state()
+    assert rel_l2(a[0], d[0]) <= TOL_F32 and rel_l2(a[1], d[1]) <= TOL_F32
