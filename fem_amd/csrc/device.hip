@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "fem_host.hpp"
@@ -175,16 +176,20 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   typedef typename Vec<T>::t4 T4;
   constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
   constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : (TPB == 1024 ? 4 : (TPB == 512 ? 2 : 1));
-  // One variant for regular and irregular meshes: the build with the wide-row loop measured 4 %
-  // FASTER on the regular 16M sphere than the one without it (same-box A/B, 213.5 vs 204.3 G
-  // DOF-it/s), so the X = false instantiation is not dispatched.
+  // Both instantiations contain the wide-row loop (a build without it measured 4 % SLOWER on the
+  // regular 16M sphere: same-box A/B, 204.3 vs 213.5 G DOF-it/s); they differ in where the wide
+  // rows' extras are staged (kernels_step.hpp): X = 2 for plans that have any, X = 1 otherwise.
   // Read-once streams go around the caches (nontemporal) only when they cannot live in the 256 MiB
   // Infinity Cache anyway: at 1M vertices (operator 230 MB) plain loads keep the operator cached
   // between launches (247 vs 210 G DOF-it/s), from 4M on the nontemporal ones win (230 vs 223 G).
   static const int proEnv = getenv("FEM_TILE_PROLOGUE") ? atoi(getenv("FEM_TILE_PROLOGUE")) : -1;   // tuning knob
   const int pro = proEnv >= 0 ? proEnv : (p->tile_bytes > (256ull << 20) ? 3 : 1);
-  auto kern = pro == 3 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 3> : pro == 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 2>
-                       : (pro == 1 ? tile_step_kernel<T, TPB, R, kTileW, MINW, true, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, true, 0>);
+  auto pick = [&](auto xtag) {
+    constexpr int XV = decltype(xtag)::value;
+    return pro == 3 ? tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 3> : pro == 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 2>
+                    : (pro == 1 ? tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 0>);
+  };
+  auto kern = p->maxExtra ? pick(std::integral_constant<int, 2>()) : pick(std::integral_constant<int, 1>());
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
                      (size_t)TPB * R * 4 * (1 + kTileW / 2);
   if (lds > 64 * 1024) {

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
 // vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
 // ---------------------------------------------------------------------------
-template <typename T, int TPB, int R, int W, int MINW, bool X, int PRO>
+template <typename T, int TPB, int R, int W, int MINW, int X, int PRO>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
@@ -231,6 +231,18 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   // 1 ids first 220.2; 2 + operator rows as nontemporal loads 222.9; 3 + index streams
   // nontemporal 224.6-228.7 G DOF-it/s (the read-once streams stop evicting the state, which
   // is the only data with reuse between tiles and launches).
+  // Wide rows' extras (entries beyond W) are staged through registers into LDS.  X == 2 (plans that
+  // have any): first of all, where the staging waits for its own loads only; after the operator
+  // loads it makes every wave wait for those before the state gathers can leave (scan8m 165 ->
+  // 170 G).  X == 1 (plans without extras, the block never runs): kept at the old place, because
+  // that build schedules the regular path 4 % faster than either alternative.
+  if (X == 2 && xcnt) {
+    for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
+    for (uint i = t; i < xcnt; i += TPB) {
+      xs_coef[i] = tcoef[W * rpad + i];
+      xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
+    }
+  }
   if (PRO >= 1) loadGhostIds(0);
 #pragma unroll
   for (int q = 0; q < R; q++) {
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
 #pragma unroll
     for (int w = 0; w < W; w++) cf[q][w] = PRO >= 2 ? ntload(&tcoef[w * rpad + r]) : tcoef[w * rpad + r];
   }
-  if (X && xcnt) {                                       // tile-uniform
+  if (X == 1 && xcnt) {                                  // tile-uniform; see X == 2 above
     for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
     for (uint i = t; i < xcnt; i += TPB) {
       xs_coef[i] = tcoef[W * rpad + i];
