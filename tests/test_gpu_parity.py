@@ -366,3 +366,36 @@ def test_config3_full_size_properties():
     p64.run(12, dt, model)
     d = p64.get_state()
     assert rel_l2(a[0], d[0]) <= TOL_F32 and rel_l2(a[1], d[1]) <= TOL_F32
+
+
+def test_edge_cases_isolated_vertices_and_tiny_meshes():
+    """vertices without faces ("0 if no incident face", mesh_function.h:61-110), a single triangle,
+    one partition, more fused steps than the mesh has rings: every path against the oracle"""
+    from helpers import Case
+    pts, tri = fa.make_icosphere(4, 0.1)
+    extra = np.array([[0.3, 0.1, -0.2], [5.0, 5.0, 5.0], [-1.0, 0.2, 0.4]])
+    pts2 = np.vstack([pts[:50], extra[:1], pts[50:], extra[1:]])          # isolated vertices in the middle and at the end
+    remap = np.concatenate([np.arange(50), np.arange(51, 51 + len(pts) - 50)])
+    tri2 = remap[tri].astype(np.uint32)
+    cases = [(pts2, tri2, 3), (np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0.0]]), np.array([[0, 1, 2]], np.uint32), 1),
+             (pts, tri, 1)]
+    for p, t, nparts in cases:
+        case = Case(p, t, nparts, seed=11)
+        st = case.ostats(ol.F64)
+        dt = 0.1 * st.maxEdgeLen ** 2
+        marr = case.model.as_array()
+        n_ref, c_ref = st.step(case.n0, case.c0, dt, 6, marr)
+        assert np.isfinite(n_ref).all()
+        case.mesh.init_stats(fa.PREC_F64)
+        for ksteps in (0, 1, 4, 8):
+            plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+            plan.set_state(case.n0, case.c0)
+            plan.run(6, dt, case.model)
+            n, c = plan.get_state()
+            assert rel_l2(n, n_ref) <= TOL_F64 and rel_l2(c, c_ref) <= TOL_F64, (len(p), ksteps)
+        lay, dev = _ref_device(case)
+        dev.set_state(case.n0, case.c0)
+        dev.run(6, dt, case.model)
+        n, c = dev.get_state()
+        n_m, c_m = case.ostats(ol.MIXED).step(case.n0, case.c0, dt, 6, marr)
+        assert rel_l2(n, n_m) <= TOL_REF and rel_l2(c, c_m) <= TOL_REF, len(p)
