@@ -5,7 +5,8 @@ One "step" = one explicit Euler time step of the whole mesh (one `step` call in 
 reference, src/FEM_common.cu:168-180; timing protocol of src/main.cpp:547-567: warm-up
 steps, then back-to-back launches with no host sync inside, device-event timed).
 
-  python bench.py --gpus 1 --steps K --warmup W [--workload sphere16m|sphere1m|sphere10k]
+  python bench.py --gpus 1 --steps K --warmup W [--workload sphere16m|sphere4m|sphere1m|sphere10k|scan8m|scan500k]
+                  [--fuse k] [--mesh FILE.off|.ply [--subdivide L]]
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
 """

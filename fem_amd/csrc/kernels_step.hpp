@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // t, t+TPB, ...: R rows x W entries x (float4 coef + 16-bit local column id)), and the workgroup
 // takes up to k time steps before writing its owned rows back: step s recomputes rows
 // [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
-// vertex-step drops from 136 B to about (1.45*108 + 1.6*8 + 8)/k B (44 B at k = 4, 1024-row tiles).
+// vertex-step drops from 136 B to about (ring ratio * 108 + ghost state/ids + 8)/k B: measured 49 B at
+// k = 4 (620-row partitions) and 45 B at k = 5 (530-row partitions) on the 16M sphere.
 // ---------------------------------------------------------------------------
 template <typename T, int TPB, int R, int W, int MINW, int X, int PRO>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   uint *xs_info = xs_off + maxExtra;                             // [T*R] rows of the register tile
   uint *xs_ix = xs_info + TPB * R;                               // X: the packed column offsets live here, not in VGPRs
   constexpr bool IXL = true;                             // packed column offsets in LDS (frees W/2*R VGPRs)
-  const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // X = false: plan without wide rows
+  const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // extras of wide rows in this tile (X = 0: never any)
   const uint t = threadIdx.x;
 
   // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
