@@ -134,11 +134,11 @@ template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
   fem_uint nb;
   if (p->ksteps > 0) {
     nb = p->ntiles;
-    hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint4 *)p->topo.p,
+    hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p,
                        p->tmeta.p, p->tghost.p, p->txinfo.p, p->rowg.p, (T4 *)p->tcoef, (fem_uint)kTileW, p->blockmax);
   } else {
     nb = p->nblocks;
-    hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint4 *)p->topo.p,
+    hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p,
                        p->slice_off.p, p->rowg.p, (T4 *)p->coef, p->nslices, p->V, p->blockmax);
   }
   hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, nb, p->maxedge);

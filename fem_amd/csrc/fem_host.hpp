@@ -126,14 +126,14 @@ struct SellLayout {
   std::vector<uint> slice_off;               // [nslices+1] entry offsets (multiples of 64)
   std::vector<uint> idx;                     // [entries]
   std::vector<double> coef;                  // [4*entries] (w, Cx, Cy, Cz)
-  std::vector<uint> topo;                    // [4*entries] RowOp::nb in layout order, for device assembly
+  std::vector<uint> topo;                    // [2*entries] RowOp::nb in layout order, for device assembly
 };
 // Folded operator in CSR form over local rows (whole mesh, or a shard's loc2glob list).
 struct RowOp {
   uint V = 0;
   std::vector<uint> rowptr, col;             // [V+1], [nnz] local column ids, ascending global order
-  std::vector<uint> nb;                      // [4*nnz] (j, o1, o2, 1): mesh ids of the neighbour and of the vertices
-                                             // opposite edge (v, j) in the faces left of v->j / j->v (~0 = none)
+  std::vector<uint> nb;                      // [2*nnz] (mesh id of neighbour j, s1 | s2 << 8 | 1 << 16): s1/s2 = row slots of
+                                             // the vertices opposite edge (v, j) in the faces left of v->j / j->v (0xff = none)
   std::vector<uint> rowg;                    // [V] mesh vertex id of each row
   std::vector<double> coef;                  // [4*nnz] (w, Cx, Cy, Cz)
 };
@@ -151,7 +151,7 @@ struct TileLayout {
   std::vector<uint> idx2;                    // packed 16-bit local column ids
   std::vector<uint> xinfo;                   // rows wider than W: per-row (first | count << 16), then column ids
   std::vector<double> coef;                  // [4*entries]
-  std::vector<uint> topo;                    // [4*entries] RowOp::nb in layout order, for device assembly
+  std::vector<uint> topo;                    // [2*entries] RowOp::nb in layout order, for device assembly
 };
 int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ranges, int ksteps, uint T, uint R,
                    uint W, uint maxLocal, uint maxExtra, TileLayout &out);

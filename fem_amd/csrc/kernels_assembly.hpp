@@ -134,17 +134,12 @@ __device__ __forceinline__ FanFace<T> fan_face(const T *e1, const T *e2) {
 // (mesh_function.h:35-110); the faces left of v's outgoing half-edges are all faces around v once,
 // so the lumped mass and the angle sum are row sums of the same quantities.  Returns the longest
 // edge at v (A4, :310-350).
+// Terms of entry (v -> j) from the edge vectors ej = j - v, e1 = o1 - v, e2 = o2 - v (o1 / o2 = the
+// vertices opposite the edge in the faces left of v->j / of j->v; has1 / has2: that face exists).
 template <typename T>
-__device__ __forceinline__ typename Vec<T>::t4 entry_terms(const typename Vec<T>::t4 *__restrict__ pos,
-                                                           const typename Vec<T>::t4 &P, uint vg, const uint4 &t, T &area3,
-                                                           T &theta, T &maxe2) {
-  typedef typename Vec<T>::t4 T4;
-  const bool real = t.w != 0u, has1 = real && t.y != ~0u, has2 = real && t.z != ~0u;
-  const T4 J = pos[real ? t.x : vg], O1 = pos[has1 ? t.y : vg], O2 = pos[has2 ? t.z : vg];
-  const T ej[3] = {J.x - P.x, J.y - P.y, J.z - P.z};
-  const T e1[3] = {O1.x - P.x, O1.y - P.y, O1.z - P.z};
-  const T e2[3] = {O2.x - P.x, O2.y - P.y, O2.z - P.z};
-  T4 a;
+__device__ __forceinline__ typename Vec<T>::t4 entry_terms(const T *ej, const T *e1, const T *e2, bool real, bool has1, bool has2,
+                                                           T &area3, T &theta, T &maxe2) {
+  typename Vec<T>::t4 a;
   a.x = a.y = a.z = a.w = 0;
   if (has1) {                                          // face (v, j, o1): p = j, q = o1
     const FanFace<T> f = fan_face<T>(ej, e1);
@@ -175,10 +170,13 @@ __device__ __forceinline__ typename Vec<T>::t4 entry_scale(const typename Vec<T>
   return o;
 }
 
-// W <= 12: fully unrolled, unnormalised terms in registers.  W = 0: any width, a plain loop that
-// parks the unnormalised terms in the output array and rescales them in a second sweep.
+// Table entry = (mesh id of the neighbour j, s1 | s2 << 8 | valid << 16): o1 and o2 are neighbours of v
+// as well, named by their slot in this row, so a row gathers each neighbour position ONCE.
+// W <= 12: fully unrolled, edge vectors and unnormalised terms in registers, o1/o2 picked by
+// compare-select chains.  W = 0: any width, a plain loop that re-gathers o1/o2 through the table
+// and parks the unnormalised terms in the output array, rescaled in a second sweep.
 template <typename T, int W, int SPLIT = W>
-__device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
+__device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
                                           typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
                                           uint width, size_t xfirst = 0) {
   typedef typename Vec<T>::t4 T4;
@@ -186,24 +184,49 @@ __device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict_
   const T4 P = pos[vg];
   T area3 = 0, theta = 0, maxe2 = 0;
   if constexpr (W > 0) {
-    uint4 t[W];
+    uint2 t[W];
 #pragma unroll
-    for (int k = 0; k < W; k++) t[k] = (uint)k < width ? topo[at(k)] : make_uint4(0u, ~0u, ~0u, 0u);
+    for (int k = 0; k < W; k++) t[k] = (uint)k < width ? topo[at(k)] : make_uint2(0u, 0xffffu);
+    T e[W][3];
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const T4 J = pos[(t[k].y >> 16) & 1u ? t[k].x : vg];
+      e[k][0] = J.x - P.x; e[k][1] = J.y - P.y; e[k][2] = J.z - P.z;
+    }
     T4 acc[W];
 #pragma unroll
-    for (int k = 0; k < W; k++) acc[k] = entry_terms<T>(pos, P, vg, t[k], area3, theta, maxe2);
+    for (int k = 0; k < W; k++) {
+      const uint s1 = t[k].y & 0xffu, s2 = (t[k].y >> 8) & 0xffu;
+      const bool real = (t[k].y >> 16) & 1u;
+      T e1[3] = {0, 0, 0}, e2[3] = {0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < W; u++) {
+        if (s1 == (uint)u) { e1[0] = e[u][0]; e1[1] = e[u][1]; e1[2] = e[u][2]; }
+        if (s2 == (uint)u) { e2[0] = e[u][0]; e2[1] = e[u][1]; e2[2] = e[u][2]; }
+      }
+      acc[k] = entry_terms<T>(e[k], e1, e2, real, real && s1 < (uint)W, real && s2 < (uint)W, area3, theta, maxe2);
+    }
 #pragma unroll
     for (int k = 0; k < W; k++)
       if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], area3, theta);
   } else {
-    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_terms<T>(pos, P, vg, topo[at(k)], area3, theta, maxe2);
+    for (int k = 0; k < (int)width; k++) {
+      const uint2 tk = topo[at(k)];
+      const uint s1 = tk.y & 0xffu, s2 = (tk.y >> 8) & 0xffu;
+      const bool real = (tk.y >> 16) & 1u, has1 = real && s1 < width, has2 = real && s2 < width;
+      const T4 J = pos[real ? tk.x : vg], O1 = pos[has1 ? topo[at((int)s1)].x : vg], O2 = pos[has2 ? topo[at((int)s2)].x : vg];
+      const T ej[3] = {J.x - P.x, J.y - P.y, J.z - P.z};
+      const T e1[3] = {O1.x - P.x, O1.y - P.y, O1.z - P.z};
+      const T e2[3] = {O2.x - P.x, O2.y - P.y, O2.z - P.z};
+      coef[at(k)] = entry_terms<T>(ej, e1, e2, real, has1, has2, area3, theta, maxe2);
+    }
     for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_scale<T>(coef[at(k)], area3, theta);
   }
   return dev_sqrt(maxe2);
 }
 
 template <typename T>
-__device__ __forceinline__ T assemble_row_wide(const typename Vec<T>::t4 *__restrict__ pos, const uint4 *__restrict__ topo,
+__device__ __forceinline__ T assemble_row_wide(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
                                                typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
                                                uint width, size_t xfirst) {
   return assemble_row<T, 0, kTileWDev>(pos, topo, coef, vg, first, stride, width, xfirst);
@@ -221,7 +244,7 @@ __device__ __forceinline__ void block_max_256(double m, double *__restrict__ blo
 
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
-                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ slice_off,
+                                                                 const uint2 *__restrict__ topo, const uint *__restrict__ slice_off,
                                                                  const uint *__restrict__ rowg,
                                                                  typename Vec<T>::t4 *__restrict__ coef, uint nslices, uint V,
                                                                  double *__restrict__ blockMax) {
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename 
 
 template <typename T>
 __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ pos,
-                                                                 const uint4 *__restrict__ topo, const uint *__restrict__ meta,
+                                                                 const uint2 *__restrict__ topo, const uint *__restrict__ meta,
                                                                  const uint *__restrict__ ghost, const uint *__restrict__ xinfo,
                                                                  const uint *__restrict__ rowg,
                                                                  typename Vec<T>::t4 *__restrict__ coef, uint W,

@@ -119,7 +119,9 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
   for (uint r = 0; r < V; r++) { const uint v = loc2glob ? loc2glob[r] : r; nnzMax += m.rowptr[v + 1] - m.rowptr[v]; }
   if (nnzMax > 0xffffffffull) return FEM_ERR_LIMIT;
   o.col.reserve(nnzMax);
-  o.nb.reserve(4 * nnzMax);
+  o.nb.reserve(2 * nnzMax);
+  std::vector<uint> opp2;                          // per entry: mesh id of the vertex opposite in the face left of j->v
+  opp2.reserve(nnzMax);
   o.rowg.resize(V);
   o.coef.reserve(4 * nnzMax);
 
@@ -138,6 +140,7 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
       const int h = m.row_he[e];
       if (h < H3) theta += s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
     }
+    const size_t rowStart = o.col.size();
     for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
       uint lc = m.col[e];
       if (loc2glob) {
@@ -161,14 +164,27 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
         for (int d = 0; d < 3; d++) C[d] /= theta;
       }
       o.col.push_back(lc);
-      // device assembly: the neighbour and the vertices opposite the edge (v, j) in the faces left
-      // of v->j and of j->v (mesh vertex ids; ~0 = no face on that side), flag 1 = real entry
+      // device assembly: the neighbour's mesh id now; the vertices opposite the edge (v, j) in the
+      // faces left of v->j and of j->v are neighbours of v too -- parked as mesh ids, turned into
+      // row slots below
       o.nb.push_back(m.col[e]);
       o.nb.push_back(h < H3 ? m.faces[SimpleTriMesh::prev_halfedge(h)] : 0xffffffffu);
-      o.nb.push_back(ho < H3 ? m.faces[SimpleTriMesh::prev_halfedge(ho)] : 0xffffffffu);
-      o.nb.push_back(1u);
+      opp2.push_back(ho < H3 ? m.faces[SimpleTriMesh::prev_halfedge(ho)] : 0xffffffffu);
       o.coef.push_back(s.wHej[h]);
       o.coef.push_back(C[0]); o.coef.push_back(C[1]); o.coef.push_back(C[2]);
+    }
+    // (j, o1, o2) -> (j, slot(o1) | slot(o2) << 8 | 1 << 16): slot = position of that neighbour among
+    // this row's entries, 0xff = no face on that side (or the neighbour lies outside the shard)
+    const size_t rowEnd = o.col.size();
+    if (rowEnd - rowStart > 254) return FEM_ERR_LIMIT;
+    for (size_t e = rowStart; e < rowEnd; e++) {
+      uint slot[2] = {0xffu, 0xffu};
+      const uint want[2] = {o.nb[2 * e + 1], opp2[e]};
+      for (int sd = 0; sd < 2; sd++)
+        if (want[sd] != 0xffffffffu)
+          for (size_t q = rowStart; q < rowEnd; q++)
+            if (o.nb[2 * q] == want[sd]) { slot[sd] = (uint)(q - rowStart); break; }
+      o.nb[2 * e + 1] = slot[0] | (slot[1] << 8) | (1u << 16);
     }
     o.rowptr[row + 1] = (uint)o.col.size();
   }
@@ -193,7 +209,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
   const size_t entries = o.slice_off[o.nslices];
   o.idx.resize(entries);
   o.coef.assign(4 * entries, 0.0);
-  o.topo.assign(4 * entries, 0u);
+  o.topo.assign(2 * entries, 0u);
   for (uint sl = 0; sl < o.nslices; sl++) {
     const uint off = o.slice_off[sl], width = (o.slice_off[sl + 1] - off) / 64;
     for (uint lane = 0; lane < 64; lane++) {
@@ -205,7 +221,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
       for (uint e = op.rowptr[row]; e < op.rowptr[row + 1]; e++, k++) {
         const size_t pos = off + (size_t)k * 64 + lane;
         o.idx[pos] = op.col[e];
-        for (int d = 0; d < 4; d++) o.topo[4 * pos + d] = op.nb[4 * (size_t)e + d];
+        o.topo[2 * pos] = op.nb[2 * (size_t)e]; o.topo[2 * pos + 1] = op.nb[2 * (size_t)e + 1];
         for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)e + d];
       }
     }
@@ -301,7 +317,7 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
     o.meta.insert(o.meta.end(), meta, meta + 16);
     o.ghost.insert(o.ghost.end(), local.begin() + m[0], local.end());
     o.coef.resize(4 * (rowOff + blockEntries), 0.0);
-    o.topo.resize(4 * (rowOff + blockEntries), 0u);
+    o.topo.resize(2 * (rowOff + blockEntries), 0u);
     o.idx2.resize((rowOff + blockEntries) / 2, 0u);
     if (xcount) o.xinfo.resize(xOff + rowsPad + xcount, 0u);
     uint xnext = 0;
@@ -321,7 +337,7 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
             o.xinfo[xOff + rowsPad + xnext] = locId[op.col[q]];
             pos = rowOff + (size_t)W * rowsPad + xnext++;
           }
-          for (int d = 0; d < 4; d++) o.topo[4 * pos + d] = op.nb[4 * (size_t)q + d];
+          o.topo[2 * pos] = op.nb[2 * (size_t)q]; o.topo[2 * pos + 1] = op.nb[2 * (size_t)q + 1];
           for (int d = 0; d < 4; d++) o.coef[4 * pos + d] = op.coef[4 * (size_t)q + d];
         }
         if (xnext > xfirst) o.xinfo[xOff + r] = xfirst | ((xnext - xfirst) << 16);
