@@ -93,6 +93,37 @@ def test_reference_step_custom_model_and_clamp():
     assert rel_l2(n_gpu, n_ref) <= 1e-6 and rel_l2(c_gpu, c_ref) <= 1e-6
 
 
+@pytest.mark.parametrize("ksteps", [0, 3])
+def test_native_plan_clamp_and_custom_model(ksteps):
+    """the max(0, .) clamp and the alt constant set on the native plans: in the deviation-form
+    state a clamped value is stored as -base, which reads back as exactly 0"""
+    case = strip_case(4)
+    case.mesh.init_stats(fa.PREC_F64)
+    model = fa.default_model()
+    model.r, model.alpha = 1.52, 12.02
+    n0, c0 = case.n0.copy(), case.c0.copy()
+    n0[::7] = 0.0
+    dt = 20 * case.dt
+    n_ref, c_ref = case.ostats(ol.F64).step(n0, c0, dt, 2, model.as_array())
+    assert (n_ref == 0).sum() > 10
+    plan = fa.Plan(case.mesh, fa.PREC_F64, model, part=case.part, ksteps=ksteps)
+    plan.set_state(n0, c0)
+    plan.run(2, dt, model)
+    n, c = plan.get_state()
+    assert np.array_equal(n == 0, n_ref == 0) and (n >= 0).all() and (c >= 0).all()
+    assert rel_l2(n, n_ref) <= TOL_F64 and rel_l2(c, c_ref) <= TOL_F64
+    # non-default nMax: the base state the deviations are taken from follows the model
+    model.nMax = 1.7
+    plan2 = fa.Plan(case.mesh, fa.PREC_F32, model, part=case.part, ksteps=ksteps)
+    nb, cb = 1.7 - (case.n0 - 1.0), 1.0 / (1.0 + 1.7 - (case.n0 - 1.0))
+    plan2.set_state(nb, cb)
+    plan2.run(5, case.dt, model)
+    n2, c2 = plan2.get_state()
+    r2 = case.ostats(ol.F64).step(nb.astype(np.float32).astype(np.float64), cb.astype(np.float32).astype(np.float64), case.dt, 5,
+                                  model.as_array())
+    assert rel_l2(n2, r2[0]) <= TOL_F32 and rel_l2(c2, r2[1]) <= TOL_F32
+
+
 def test_reference_step_limits_and_errors():
     case = sphere_case(4, 1)            # one partition, 162 vertices, 320 faces
     lay, dev = _ref_device(case)
