@@ -197,8 +197,8 @@ class ShardedRun:
                 # the exchange has had the previous group's interior launch to finish: if it has,
                 # this group is ONE launch (no short boundary launch with its tail); if not, the
                 # interior tiles go first and the wait comes after them
-                done = self.pending is None or getattr(self.pending, "is_completed", lambda: False)()
-                if not self.force_split and done:
+                arrived = self.pending is None or getattr(self.pending, "is_completed", lambda: False)()
+                if not self.force_split and arrived:
                     self._wait_exchange()
                     merged = True
                 else:

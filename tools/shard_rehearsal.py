@@ -21,7 +21,7 @@ world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 krings = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 400
-nu = {"sphere16m": 1280, "sphere4m": 640, "sphere1m": 320}[wl]
+nu = {"sphere16m": 1280, "sphere4m": 640, "sphere1m": 320, "scan8m": 900, "scan500k": 224}[wl]
 fuse = int(os.environ.get("FEM_FUSE_STEPS", "5"))
 
 
@@ -40,11 +40,11 @@ def stub_exchange(stepper, shard, stream=None, group=None, which=0, async_op=Fal
 
 
 fdist.exchange_halo = stub_exchange
-pts, tri = fa.make_icosphere(nu, 0.1)
+pts, tri = fa.make_scanned_like(nu, 0.1, seed=3) if wl.startswith("scan") else fa.make_icosphere(nu, 0.1)
 mesh = fa.Mesh(pts, tri)
 V = mesh.V
 run = fdist.ShardedRun(mesh, max(world, V // int(os.environ.get("FEM_TILE_N0", {4: "620", 5: "530"}.get(fuse, "620")))), rank, world, "f32", krings=krings,
-                       ksteps=fuse)
+                       ksteps=fuse, dt_rule="stable" if wl.startswith("scan") else "reference")
 del pts, tri, mesh
 stream = torch.cuda.current_stream()
 run.run(2 * krings, stream)
