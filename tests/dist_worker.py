@@ -31,7 +31,13 @@ rank, world = dist.get_rank(), dist.get_world_size()
 make = None
 stream = None
 if a.backend == "oracle":
-    from shard_oracle import OracleShardStepper as make
+    if a.fuse > 0:                                 # drives the overlapped tile schedule of ShardedRun on the CPU
+        from shard_oracle import OracleTileStepper
+
+        def make(*args):
+            return OracleTileStepper(*args, ksteps=a.fuse)
+    else:
+        from shard_oracle import OracleShardStepper as make
 else:
     torch.cuda.set_device(0)                      # all ranks share the one GPU of the test box
     stream = torch.cuda.current_stream()
@@ -43,6 +49,7 @@ run.run(a.steps // 2, stream)
 run.run(a.steps - a.steps // 2, stream)
 n, c = run.get_owned()
 np.savez(a.out + ".%d.npz" % rank, n=n, c=c, own_begin=run.shard.own_begin, own_end=run.shard.own_end, dt=run.dt,
-         classes=np.array(run.classes if run.classes is not None else (-1, -1, -1)))
+         classes=np.array(run.classes if run.classes is not None else (-1, -1, -1)),
+         launches=np.array(getattr(run.stepper, "launch_log", []) or [(-1, -1, -1)]))
 dist.barrier()
 dist.destroy_process_group()

@@ -59,6 +59,39 @@ def test_gloo_oracle_stepper(world, krings, steps, tmp_path):
     assert covered == part.ordered.V
 
 
+@pytest.mark.parametrize("world,krings,fuse,steps,overlap", [
+    (2, 4, 2, 11, "1"),        # merged first group (the exchange is synchronous here, so it has always arrived)
+    (2, 4, 2, 11, "split"),    # interior first, wait, boundary + ghost
+    (3, 3, 3, 10, "split"),    # one group per exchange
+    (3, 3, 3, 10, "1"),
+    (2, 6, 4, 13, "1"),        # groups of 4 + 2
+    (2, 4, 2, 11, "0"),        # plain schedule through the same stepper
+])
+def test_gloo_overlapped_schedule_on_oracle_tiles(world, krings, fuse, steps, overlap, tmp_path, monkeypatch):
+    """the [interior | boundary | ghost] schedule of ShardedRun (fem_amd/dist.py) without a GPU:
+    an oracle-backed stepper with two buffers, stale rows where a tile was not launched and NaN
+    where nothing was ever written"""
+    nu, nparts = 24, 10
+    part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
+    monkeypatch.setenv("FEM_OVERLAP", overlap)
+    res = launch(world, tmp_path, backend="oracle", sphere=nu, nparts=nparts, krings=krings, steps=steps, fuse=fuse)
+    for r in res:
+        b, e = int(r["own_begin"]), int(r["own_end"])
+        assert not np.isnan(r["n"]).any() and not np.isnan(r["c"]).any()
+        assert rel_l2(r["n"], n_ref[b:e]) <= 1e-13 and rel_l2(r["c"], c_ref[b:e]) <= 1e-13
+        if overlap == "0":
+            assert tuple(r["classes"]) == (-1, -1, -1)
+        else:
+            nI, nB, nG = r["classes"]
+            assert nI > 0 and nB > 0 and nG > 0
+            ranges = {(int(f), int(c)) for f, c, _ in r["launches"]}
+            assert (nI, nB) in ranges and (0, nI) in ranges        # boundary-only and interior-only launches happened
+            if overlap == "split":
+                assert (nI, nB + nG) in ranges
+            else:
+                assert (0, nI + nB + nG) in ranges
+
+
 def test_shard_lists_are_consistent():
     pts, tri = fa.make_icosphere(12, 0.1)
     part = fa.Mesh(pts, tri).partition(10)
