@@ -237,7 +237,7 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
                        p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, p->nslices, p->nblocks, dtDn, dtDc, 1, p->ix_partial);
     hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbs, p->ix_sc, 0);
     for (int it = 0; it < iters; it++) {
-      hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)p->ix_p, (T2 *)p->ix_q, (T2 *)p->ix_r, (T2 *)p->ix_p,
+      hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)p->ix_p, (T2 *)p->ix_q, (T2 *)nullptr, (T2 *)nullptr,
                          p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, p->nslices, p->nblocks, dtDn, dtDc, 0, p->ix_partial);
       hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbs, p->ix_sc, 1);
       hipLaunchKernelGGL(imex_update_kernel<T>, dim3(nbv), dim3(256), 0, st, x, (T2 *)p->ix_r, (const T2 *)p->ix_p, (const T2 *)p->ix_q,
@@ -426,6 +426,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   if (ksteps > 0 && (!node_parts || n < 1)) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partition ranges missing");
   if ((flags & FEM_PLAN_IMPLICIT) && (ksteps > 0 || shard))
     return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT needs a sliced-ELL plan of a whole mesh (ksteps = 0, no shard)");
+  if ((flags & FEM_PLAN_IMPLICIT) && (flags & FEM_PLAN_DEVICE_ASSEMBLY))
+    return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT takes the lumped masses from the host assembly; not combinable with FEM_PLAN_DEVICE_ASSEMBLY");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");

@@ -246,7 +246,7 @@ int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_p
  * be re-assembled there (fem_plan_assemble) -- initMeshStats on the GPU, mesh_function.cpp:27-67.
  * ksteps = 0: sliced-ELL layout; n/node_parts may then be 0/NULL. */
 #define FEM_PLAN_DEVICE_ASSEMBLY 1u
-#define FEM_PLAN_IMPLICIT 2u          /* sliced-ELL plan of a whole mesh: enables fem_plan_run_imex */
+#define FEM_PLAN_IMPLICIT 2u          /* sliced-ELL plan of a whole mesh: enables fem_plan_run_imex (not with DEVICE_ASSEMBLY) */
 int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                        const fem_shard *shard, int precision, const fem_model *model, int ksteps,
                        unsigned flags, fem_plan **out);
