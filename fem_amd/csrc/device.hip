@@ -610,6 +610,7 @@ int fem_plan_pack_halo_from(fem_plan *p, int which, uint64_t dst_dev, void *stre
 
 int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn) {
   if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_set_state: null");
+  HIP_TRY(hipDeviceSynchronize());
   if (p->precision == FEM_PREC_F32) {
     std::vector<float> h(2 * (size_t)p->V);
     for (size_t i = 0; i < p->V; i++) { h[2 * i] = (float)(nFn[i] - p->base_n); h[2 * i + 1] = (float)(cFn[i] - p->base_c); }
@@ -815,7 +816,8 @@ int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *r
   const fem_uint V = nverts, nb = std::min<fem_uint>((V + 255) / 256, 1024);
   double *part = nullptr, *mm = nullptr;
   double4 *out = nullptr;
-  hipError_t e = hipMalloc((void **)&part, 16 * (size_t)nb);
+  hipError_t e = hipDeviceSynchronize();      // steps may still be in flight on a non-blocking stream
+  if (e == hipSuccess) e = hipMalloc((void **)&part, 16 * (size_t)nb);
   if (e == hipSuccess) e = hipMalloc((void **)&mm, 16);
   if (e == hipSuccess) e = hipMalloc((void **)&out, sizeof(double4) * (size_t)V);
   if (e == hipSuccess) {
