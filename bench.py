@@ -96,14 +96,27 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    local_dev = local_rank % torch.cuda.device_count() if args.dist_backend == "gloo" else local_rank
+    share = args.dist_backend == "gloo" or os.environ.get("FEM_BENCH_SHARE_GPU") == "1"   # rehearsals only
+    local_dev = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(local_dev)
+    control = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_dev))
+            # RCCL communicator comes up at the first collective (ShardedRun's priming exchange);
+            # the gloo control group lets all ranks agree on the host-staged fallback if it cannot
+            dist.init_process_group("nccl")
+            control = dist.new_group(backend="gloo")
         else:
             dist.init_process_group("gloo")
+
+    def rank_barrier():
+        if control is not None and getattr(runner, "host_group", None) is not None:
+            dist.all_reduce(torch.zeros(1), group=control)
+        elif args.dist_backend == "nccl":
+            dist.barrier(device_ids=[local_dev])
+        else:
+            dist.barrier()
 
     wl = WORKLOADS[args.workload] if args.mesh is None else dict(nu=0, verts_per_part=256, scanned=True)
     if args.fuse is None:
@@ -124,7 +137,8 @@ def main():
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     if world > 1:
         from fem_amd import dist as fdist
-        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse, dt_rule=dt_rule)
+        runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse, dt_rule=dt_rule,
+                                  control_group=control)
     else:
         from fem_amd import dist as fdist
         runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse, dt_rule=dt_rule)
@@ -145,7 +159,7 @@ def main():
     runner.run(args.warmup, stream)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        rank_barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -154,13 +168,15 @@ def main():
     ev1.record(stream)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        rank_barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        tmax = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        staged = getattr(runner, "host_group", None)
+        tmax = torch.tensor([wall, dev_ms], dtype=torch.float64,
+                            device="cuda" if args.dist_backend == "nccl" and staged is None else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=staged)
         wall, dev_ms = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
@@ -185,7 +201,9 @@ def main():
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report,
-                       "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange" % world},
+                       "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange%s" % (
+                           world, "" if getattr(runner, "fallback_reason", None) is None else
+                           " STAGED THROUGH THE HOST over gloo (RCCL did not come up: %s)" % runner.fallback_reason)},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_rate": traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None,

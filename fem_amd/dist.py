@@ -106,18 +106,21 @@ class HipShardStepper:
         return n[:self.shard.n_own], c[:self.shard.n_own]
 
 
-def exchange_halo(stepper, shard, stream=None, group=None, which=0, async_op=False):
+def exchange_halo(stepper, shard, stream=None, group=None, which=0, async_op=False, host_group=None):
     """one all-to-all-v of boundary state: each rank's send vertices -> the ghost segments of its
     neighbours' state buffers (which = 0 current, 1 next).  RCCL (backend nccl) moves device
     memory directly and, with async_op, returns a work handle: kernels launched afterwards on the
-    compute stream run beside the exchange until handle.wait().  With gloo (CPU tests, or several
-    ranks sharing one GPU) the buffers are staged through the host, synchronously."""
+    compute stream run beside the exchange until handle.wait().  With gloo (CPU tests, several
+    ranks sharing one GPU, or `host_group` = the gloo group ShardedRun falls back to when RCCL
+    cannot be brought up) the buffers are staged through the host, synchronously."""
     import torch
     import torch.distributed as dist
     send = stepper.pack(stream, which) if which else stepper.pack(stream)
     recv = stepper.ghost_view(which) if which else stepper.ghost_view()
     in_splits, out_splits = [int(x) for x in shard.send_counts], [int(x) for x in shard.recv_counts]
-    if dist.get_backend(group) == "gloo" and send.is_cuda:
+    if host_group is not None:
+        group = host_group
+    if send.is_cuda and (host_group is not None or dist.get_backend(group) == "gloo"):
         torch.cuda.synchronize()
         send_h, recv_h = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
         dist.all_to_all_single(recv_h, send_h, out_splits, in_splits, group=group)
@@ -131,7 +134,7 @@ class ShardedRun:
     """the mesh split along the partition ranges over `world` ranks; k ghost rings let every rank
     take k steps between two halo exchanges (communication-avoiding explicit stepping)"""
     def __init__(self, mesh, nparts, rank, world, precision="f32", seed=1, krings=None, make_stepper=None,
-                 ksteps=0, dt_rule="reference"):
+                 ksteps=0, dt_rule="reference", control_group=None):
         self.ksteps = ksteps
         self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
         self.steps_per_launch = max(1, ksteps)
@@ -158,10 +161,32 @@ class ShardedRun:
         self.classes = tc() if (tc is not None and os.environ.get("FEM_OVERLAP", "1") != "0") else None
         self.force_split = os.environ.get("FEM_OVERLAP", "1") == "split"   # tests: always take the not-yet-arrived path
         # one exchange up front (re-sends the ghosts' own initial values): brings up the RCCL
-        # communicator and its buffers outside any timed region
+        # communicator and its buffers outside any timed region.  `control_group` (a gloo group over
+        # the same ranks) makes that bring-up survivable: if RCCL raises here on any rank, all ranks
+        # agree over gloo to stage every exchange through the host instead (slower, same results;
+        # `host_group`/`fallback_reason` say so and bench.py reports it).
         import torch.distributed as dist
+        self.host_group, self.fallback_reason = None, None
         if dist.is_available() and dist.is_initialized() and world > 1:
-            exchange_halo(self.stepper, self.shard, None)
+            err = None
+            try:
+                exchange_halo(self.stepper, self.shard, None)
+                if control_group is not None:
+                    import torch
+                    torch.cuda.synchronize()
+            except Exception as ex:                    # noqa: BLE001 (reported below or re-raised)
+                if control_group is None:
+                    raise
+                err = ex
+            if control_group is not None:
+                import torch
+                failed = torch.tensor([0 if err is None else 1])
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=control_group)
+                if int(failed.item()):
+                    self.host_group = control_group
+                    self.fallback_reason = ("%s: %s" % (type(err).__name__, str(err).strip().splitlines()[0][:160])
+                                            if err is not None else "RCCL failed on another rank")
+                    exchange_halo(self.stepper, self.shard, None, host_group=control_group)
         self.vertices_per_launch = self.shard.n_local
         sb = 4 if precision == "f32" else 8
         plan = self.plan
@@ -173,7 +198,7 @@ class ShardedRun:
         done = 0
         while done < nsteps:
             if self.budget == 0:
-                exchange_halo(self.stepper, self.shard, stream)
+                exchange_halo(self.stepper, self.shard, stream, host_group=self.host_group)
                 self.budget = self.krings
             chunk = min(self.budget, nsteps - done)
             self.stepper.step(chunk, self.dt, self.model, stream)
@@ -206,7 +231,7 @@ class ShardedRun:
                     self._wait_exchange()
             if last:
                 st.launch(nI, nB, s, dt, model, stream)
-                self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=True)
+                self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=True, host_group=self.host_group)
                 self.pending_exchange = True
                 if not first or merged:
                     st.launch(0, nI, s, dt, model, stream)

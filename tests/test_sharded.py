@@ -226,3 +226,23 @@ def test_gpu_tile_classes():
         plan.launch_tiles(0, 1, 4, dt)                      # more steps than the plan fuses
     with pytest.raises(fa.FemError):
         fa.Plan(om, fa.PREC_F64).tile_classes()             # sliced-ELL plan
+
+
+@pytest.mark.gpu
+def test_bench_survives_rccl_bringup_failure():
+    """bench.py as the driver launches it for N > 1 (backend nccl), but with both ranks on ONE GPU
+    (FEM_BENCH_SHARE_GPU=1): RCCL refuses duplicate devices at its first collective, the ranks agree
+    over the gloo control group to stage the exchange through the host, and the bench still reports
+    -- saying so in config.parallelism."""
+    import json
+    _launches[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + (os.getpid() * 16 + _launches[0]) % 2000),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "2", "--workload", "sphere10k"]
+    env = dict(os.environ, FEM_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    res = subprocess.run(cmd, check=True, timeout=150, env=env, capture_output=True, text=True)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
+    assert "STAGED THROUGH THE HOST" in out["config"]["parallelism"]
