@@ -259,6 +259,19 @@ extern "C" {
 int fem_last_error(void) { return fem::g_last_error; }
 const char *fem_error_detail(void) { return fem::g_error_detail.c_str(); }
 
+int fem_device_synchronize(void) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+int fem_device_download(void *host_dst, uint64_t dev_src, size_t bytes) {
+  if (bytes == 0) return FEM_OK;
+  if (!host_dst || !dev_src) return fail(FEM_ERR_INVALID, "fem_device_download: null");
+  HIP_TRY(hipMemcpy(host_dst, (const void *)dev_src, bytes, hipMemcpyDeviceToHost));
+  return FEM_OK;
+}
+
 int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_weights,
              fem_uint fv_pitchInBytes, fem_uint fvw_pitchInBytes, fem_uint *nbr, double *vtxW,
              fem_uint vw_pitchInBytes, double *vertex_weights, fem_uint vv_pitchInBytes,

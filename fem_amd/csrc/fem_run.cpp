@@ -1,0 +1,308 @@
+// fem_run -- command-line driver over the C-ABI (include/fem_hip.h only; no HIP header, no Python).
+//
+// The caller side of the hot path, as the reference has it in src/main.cpp:
+//   main            (main.cpp:116-154)  mesh file [-d], loop over partition counts, "Best time ..."
+//   initializeData  (main.cpp:169-192)  partition -> initMeshStats -> IC -> dt = 0.1 maxEdgeLen^2
+//   initializeGPUData (main.cpp:207-342) -> fem_ref_layout_create
+//   GPUrun, non-visual path (main.cpp:344-617): limits, uploads, two warm-up `step`s, the check
+//                   against CPUrun, then maxIt x 2 back-to-back `step`s between two time stamps
+//   CPUrun          (main.cpp:619-676)  host steps from the three compute*CPU operators
+// What differs, on purpose: the check uses the kernel's constants (the reference's host constants
+// differ from its kernel's, so its own error counts mean nothing) and compares round 2 with TWO host
+// steps (the reference restarts CPUrun from the initial state); the IC is seeded; --native runs the
+// same protocol on the native fp32 plan; --out writes the colour pattern (ResultantPattern.off's shape).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fem_hip.h"
+
+namespace {
+
+struct Options {
+  std::string file, out;
+  bool debug = false, verbose = false, native = false, hostConstants = false;
+  int startN = 52, endN = 52;        // main.cpp:100-101
+  int maxIt = 1000;                  // main.cpp:548
+  int fuse = 5, rowsPerPart = 530;   // native plan: fused steps per launch, rows per partition
+  unsigned seed = 1;
+};
+
+struct Run {                         // what initializeData leaves behind
+  fem_mesh *ordered = nullptr;
+  std::vector<fem_uint> nodeParts, elementParts;
+  std::vector<double> nFn, cFn;
+  double dt = 0;
+  int V = 0, F = 0;
+  ~Run() { fem_mesh_destroy(ordered); }
+};
+
+bool ok(int rc, const char *what) {
+  if (rc >= 0) return true;
+  std::fprintf(stderr, "%s: %s (%s)\n", what, fem_error_string(rc), fem_error_detail());
+  return false;
+}
+
+bool endsWith(const std::string &s, const char *suffix) {
+  const size_t n = std::strlen(suffix);
+  return s.size() >= n && !strcasecmp(s.c_str() + s.size() - n, suffix);
+}
+
+fem_mesh *loadMesh(const Options &o) {
+  int V = 0, F = 0;
+  double *pts = nullptr;
+  fem_uint *tri = nullptr;
+  unsigned char *rgb = nullptr;
+  const int rc = endsWith(o.file, ".ply") ? fem_ply_read(o.file.c_str(), &V, &F, &pts, &tri, &rgb)
+                                          : fem_off_read(o.file.c_str(), &V, &F, &pts, &tri, &rgb);
+  if (!ok(rc, o.file.c_str())) return nullptr;
+  fem_mesh *m = nullptr;
+  const bool made = ok(fem_mesh_create(V, F, pts, tri, &m), "mesh");
+  fem_free(pts); fem_free(tri); fem_free(rgb);
+  return made ? m : nullptr;
+}
+
+bool initializeData(const fem_mesh *original, int n, const Options &o, const fem_model &model, Run &r) {
+  fem_mesh_counts(original, &r.V, &r.F, nullptr);
+  std::vector<int64_t> permV(r.V), permF(r.F);
+  r.nodeParts.resize(n + 1); r.elementParts.resize(n + 2);
+  if (!ok(fem_partition(original, n, permV.data(), permF.data(), r.nodeParts.data(), r.elementParts.data(), &r.ordered), "partition"))
+    return false;
+  if (!ok(fem_mesh_init_stats(r.ordered, o.native ? FEM_PREC_F64 : FEM_PREC_MIXED), "initMeshStats")) return false;
+  double maxEdge = 0;
+  if (!ok(fem_mesh_stats(r.ordered, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &maxEdge, nullptr, nullptr), "stats")) return false;
+  r.nFn.resize(r.V); r.cFn.resize(r.V);
+  fem_initial_condition(r.V, o.seed, model.nMax, r.nFn.data(), r.cFn.data());
+  r.dt = 0.1 * maxEdge * maxEdge;
+  return true;
+}
+
+// CPUrun: `steps` host steps from the initial state, into n/c
+bool hostRun(const Run &r, const fem_model &m, int steps, std::vector<double> &n, std::vector<double> &c) {
+  n = r.nFn; c = r.cFn;
+  std::vector<double> lapN(r.V), lapC(r.V), faceG(3 * (size_t)r.F), gradN(3 * (size_t)r.V), gradC(3 * (size_t)r.V);
+  for (int s = 0; s < steps; s++) {
+    if (fem_compute_laplacian_cpu(r.ordered, n.data(), lapN.data()) < 0 ||
+        fem_compute_laplacian_cpu(r.ordered, c.data(), lapC.data()) < 0 ||
+        fem_compute_face_gradients_cpu(r.ordered, n.data(), faceG.data()) < 0 ||
+        fem_compute_vertex_gradients_cpu(r.ordered, faceG.data(), gradN.data()) < 0 ||
+        fem_compute_face_gradients_cpu(r.ordered, c.data(), faceG.data()) < 0 ||
+        fem_compute_vertex_gradients_cpu(r.ordered, faceG.data(), gradC.data()) < 0)
+      return ok(fem_last_error(), "CPUrun");
+    for (int j = 0; j < r.V; j++) {
+      const float dot = (float)gradC[3 * j] * (float)gradN[3 * j] + (float)gradC[3 * j + 1] * (float)gradN[3 * j + 1] +
+                        (float)gradC[3 * j + 2] * (float)gradN[3 * j + 2];
+      const double dn = m.D * lapN[j] - m.alpha * n[j] * lapC[j] - m.alpha * dot + m.S * m.r * n[j] * (m.nMax - n[j]);
+      const double dc = lapC[j] + m.S * (-c[j] + n[j] / (1 + n[j]));
+      n[j] = std::max(0.0, n[j] + r.dt * dn);
+      c[j] = std::max(0.0, c[j] + r.dt * dc);
+    }
+  }
+  return true;
+}
+
+int reportRound(int round, const std::vector<double> &gn, const std::vector<double> &gc, const std::vector<double> &hn,
+                const std::vector<double> &hc, bool print) {
+  double sumN = 0, sumC = 0;
+  int errors = 0;
+  const int V = (int)gn.size();
+  for (int i = 0; i < V; i++) {
+    if (std::isnan(hn[i])) continue;
+    const double en = std::fabs(gn[i] - hn[i]), ec = std::fabs(gc[i] - hc[i]);
+    sumN += en; sumC += ec;
+    if (en > 0 || ec > 0) errors++;
+  }
+  if (print)
+    std::printf("Round %d: Sum / Mean error for n: %g / %g and for c: %g / %g. Number of errors in total: %d(%d)\n", round,
+                sumN, sumN / V, sumC, sumC / V, errors, V);
+  return errors;
+}
+
+void writePattern(const Options &o, const Run &r, const std::vector<double> &n, const std::vector<double> &c) {
+  // format(): min/max + colour map on the device (fem_plan_format), then the COFF file
+  fem_plan *plan = nullptr;
+  if (!ok(fem_plan_create(r.ordered, FEM_PREC_F64, nullptr, &plan), "format plan")) return;
+  std::vector<unsigned char> rgb(3 * (size_t)r.V);
+  double lo = 0, hi = 0;
+  const double *pts = nullptr;
+  const fem_uint *tri = nullptr;
+  fem_mesh_arrays(r.ordered, &pts, &tri);
+  if (ok(fem_plan_set_state(plan, n.data(), c.data()), "format") &&
+      ok(fem_plan_format(plan, (fem_uint)r.V, nullptr, rgb.data(), &lo, &hi), "format") &&
+      ok(fem_off_write(o.out.c_str(), r.V, r.F, pts, tri, rgb.data()), o.out.c_str()))
+    std::printf("Pattern written to %s (n in [%g, %g])\n", o.out.c_str(), lo, hi);
+  fem_plan_destroy(plan);
+}
+
+double seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// GPUrun, non-visual: returns microseconds per step, -1 on a limit or error
+double gpuRun(int n, const Options &o, const fem_model &model, const Run &r) {
+  fem_ref_layout *lay = nullptr;
+  fem_ref_device *dev = nullptr;
+  if (!ok(fem_ref_layout_create(r.ordered, n, r.nodeParts.data(), r.elementParts.data(), &lay), "initializeGPUData")) return -1;
+  const int rc = fem_ref_device_create(lay, r.nodeParts.data(), r.V, &dev);
+  fem_ref_layout_destroy(lay);
+  if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -1; }      // main.cpp:357-364
+  if (!ok(rc, "GPUrun")) return -1;
+
+  std::vector<fem_double2> fn(r.V);
+  for (int i = 0; i < r.V; i++) { fn[i].x = r.nFn[i]; fn[i].y = r.cFn[i]; }
+  double usPerStep = -1;
+  uint64_t one, two, fv, fvw, nbr, vtxW, vw, grads, parts, bfc;
+  fem_uint fvPitch, fvwPitch, vwPitch, vvPitch, vwsPitch, vvSize, hePitch, blocks, threads, smem;
+  fem_ref_device_args(dev, &one, &two, &fv, &fvw, &fvPitch, &fvwPitch, &nbr, &vtxW, &vwPitch, &vw, &vvPitch, &vwsPitch,
+                      &vvSize, &grads, &hePitch, &parts, &bfc, &blocks, &threads, &smem);
+  auto doStep = [&](uint64_t src, uint64_t dst) {
+    step((fem_double2 *)src, (fem_double2 *)dst, (fem_uint *)fv, (double *)fvw, fvPitch, fvwPitch, (fem_uint *)nbr,
+         (double *)vtxW, vwPitch, (double *)vw, vvPitch, vwsPitch, vvSize, (fem_float4 *)grads, hePitch, (fem_uint *)parts,
+         (fem_uint *)bfc, blocks, threads, r.dt, smem);
+  };
+  auto download = [&](uint64_t src, std::vector<double> &gn, std::vector<double> &gc) {
+    if (!ok(fem_device_download(fn.data(), src, sizeof(fem_double2) * (size_t)r.V), "read-back")) return false;
+    gn.resize(r.V); gc.resize(r.V);
+    for (int i = 0; i < r.V; i++) { gn[i] = fn[i].x; gc[i] = fn[i].y; }
+    return true;
+  };
+  do {
+    if (!ok(fem_ref_device_set_state(dev, fn.data()), "upload")) break;
+    doStep(one, two);
+    doStep(two, one);
+    if (!ok(fem_device_synchronize(), "step") || !ok(fem_last_error(), "step")) break;
+
+    // Correctness test (main.cpp:492-541)
+    std::vector<double> gn, gc, hn, hc;
+    int errors = 0;
+    if (!hostRun(r, model, 1, hn, hc) || !download(two, gn, gc)) break;
+    reportRound(1, gn, gc, hn, hc, o.verbose || o.debug);
+    if (!hostRun(r, model, 2, hn, hc) || !download(one, gn, gc)) break;
+    errors = reportRound(2, gn, gc, hn, hc, o.verbose || o.debug);
+    if (o.debug) { usPerStep = 0; break; }
+
+    // Speed test (main.cpp:547-575): maxIt x 2 launches, nothing in between
+    const double t0 = seconds();
+    for (int i = 0; i < o.maxIt; i++) { doStep(one, two); doStep(two, one); }
+    if (!ok(fem_device_synchronize(), "step")) break;
+    const double ms = (seconds() - t0) * 1e3 / 2;
+    usPerStep = 1000 * ms / o.maxIt;
+    if (o.verbose) {
+      std::printf("Time needed for %d iterations: %f ms with %u threads each and %d partitions\n", o.maxIt, ms, threads, n);
+      std::printf("Average time needed per Iteration: %f us\n", usPerStep);
+    } else {
+      std::printf("Errors: %d, Partitions: %d, Threads: %u, Time: %f\n", errors, n, threads, usPerStep);
+    }
+    if (!o.out.empty() && download(one, gn, gc)) writePattern(o, r, gn, gc);
+  } while (false);
+  fem_ref_device_destroy(dev);
+  return usPerStep;
+}
+
+// the same protocol on the native fp32 plan (fused tiles; fuse = 0: sliced ELL)
+double nativeRun(int n, const Options &o, const fem_model &model, const Run &r) {
+  fem_plan *plan = nullptr;
+  const int rc = o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), nullptr, FEM_PREC_F32, &model, o.fuse, &plan)
+                            : fem_plan_create(r.ordered, FEM_PREC_F32, &model, &plan);
+  if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -1; }
+  if (!ok(rc, "plan")) return -1;
+  double usPerStep = -1;
+  do {
+    std::vector<double> gn(r.V), gc(r.V), hn, hc;
+    if (!ok(fem_plan_set_state(plan, r.nFn.data(), r.cFn.data()), "upload")) break;
+    if (!ok(fem_plan_run(plan, 2, r.dt, &model, nullptr), "step") || !ok(fem_plan_get_state(plan, gn.data(), gc.data()), "read-back")) break;
+    if (!hostRun(r, model, 2, hn, hc)) break;
+    const int errors = reportRound(2, gn, gc, hn, hc, o.verbose || o.debug);
+    if (o.debug) { usPerStep = 0; break; }
+    const double t0 = seconds();
+    if (!ok(fem_plan_run(plan, 2 * o.maxIt, r.dt, &model, nullptr), "step") || !ok(fem_device_synchronize(), "step")) break;
+    const double ms = (seconds() - t0) * 1e3 / 2;
+    usPerStep = 1000 * ms / o.maxIt;
+    int threads = 0;
+    fem_plan_tile_info(plan, nullptr, nullptr, nullptr, nullptr, &threads, nullptr);
+    if (o.verbose) {
+      std::printf("Time needed for %d iterations: %f ms with %d threads each and %d partitions\n", o.maxIt, ms, threads, n);
+      std::printf("Average time needed per Iteration: %f us\n", usPerStep);
+    } else {
+      std::printf("Errors: %d, Partitions: %d, Threads: %d, Time: %f\n", errors, n, threads, usPerStep);
+    }
+    if (!o.out.empty() && ok(fem_plan_get_state(plan, gn.data(), gc.data()), "read-back")) writePattern(o, r, gn, gc);
+  } while (false);
+  fem_plan_destroy(plan);
+  return usPerStep;
+}
+
+int usage() {
+  std::fprintf(stderr,
+               "usage: fem_run MESH.off|MESH.ply [-d] [-v] [-n PARTS | -n FIRST:LAST] [--iterations N] [--seed S]\n"
+               "               [--native [--fuse K] [--rows R]] [--host-constants] [--out PATTERN.off]\n"
+               "  -d               check only (two steps against the host operators), as the reference's -d\n"
+               "  -v               the reference's verbose prints\n"
+               "  -n               partition counts to try (default 52, the reference's start_n..end_n)\n"
+               "  --iterations     timed iterations of two steps each (default 1000)\n"
+               "  --native         native fp32 plan instead of step() on the reference layout; partitions of R rows\n"
+               "                   (default 530) unless -n is given, K fused steps per launch (default 5, 0 = one)\n"
+               "  --host-constants r = 1.52, alpha = 12.02 (main.cpp:49-54) instead of the kernel's set; native only\n"
+               "  --out            write the coloured result (COFF)\n");
+  return 2;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+  Options o;
+  bool partsGiven = false;
+  for (int i = 1; i < argc; i++) {
+    const std::string a = argv[i];
+    auto value = [&]() -> const char * { return i + 1 < argc ? argv[++i] : nullptr; };
+    if (a == "-d") o.debug = true;
+    else if (a == "-v") o.verbose = true;
+    else if (a == "--native") o.native = true;
+    else if (a == "--host-constants") o.hostConstants = true;
+    else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out") {
+      const char *v = value();
+      if (!v) return usage();
+      if (a == "-n") {
+        partsGiven = true;
+        o.startN = o.endN = std::atoi(v);
+        if (const char *colon = std::strchr(v, ':')) o.endN = std::atoi(colon + 1);
+      } else if (a == "--iterations") o.maxIt = std::atoi(v);
+      else if (a == "--seed") o.seed = (unsigned)std::strtoul(v, nullptr, 10);
+      else if (a == "--fuse") o.fuse = std::atoi(v);
+      else if (a == "--rows") o.rowsPerPart = std::atoi(v);
+      else o.out = v;
+    } else if (!a.empty() && a[0] == '-') return usage();
+    else if (o.file.empty()) o.file = a;
+    else return usage();
+  }
+  if (o.file.empty() || o.startN < 1 || o.endN < o.startN || o.maxIt < 1 || o.fuse < 0 || o.fuse > 8 || o.rowsPerPart < 1 ||
+      (o.hostConstants && !o.native))
+    return usage();
+
+  fem_model model;
+  fem_default_model(&model);
+  if (o.hostConstants) { model.r = 1.52; model.alpha = 12.02; }
+
+  fem_mesh *original = loadMesh(o);
+  if (!original) return 1;
+  int V = 0;
+  fem_mesh_counts(original, &V, nullptr, nullptr);
+  if (o.native && !partsGiven) o.startN = o.endN = std::max(1, V / o.rowsPerPart);
+
+  double bestTime = 0;
+  int bestN = -1;
+  for (int n = o.startN; n <= o.endN; n++) {
+    Run r;
+    if (!initializeData(original, n, o, model, r)) { fem_mesh_destroy(original); return 1; }
+    const double t = o.native ? nativeRun(n, o, model, r) : gpuRun(n, o, model, r);
+    if ((bestN == -1 || bestTime > t) && t > 0) { bestN = n; bestTime = t; }
+  }
+  if (!o.debug) std::printf("Best time with %d partitions is %.1f!\n", bestN, bestTime);
+  fem_mesh_destroy(original);
+  return 0;
+}

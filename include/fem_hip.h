@@ -84,6 +84,13 @@ int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_
              fem_uint blocks, double dt, fem_uint max_part_vertices, const fem_model *model,
              void *stream);
 
+/* For callers of step() that include no HIP header: the reference caller's
+ * cudaDeviceSynchronize() + cudaGetLastError() after the warm-up steps
+ * (main.cpp:487-490) and its result read-backs cudaMemcpy(..., DeviceToHost)
+ * (main.cpp:499,525; blocking, default stream). */
+int fem_device_synchronize(void);
+int fem_device_download(void *host_dst, uint64_t dev_src, size_t bytes);
+
 /* ------------------------------------------------------------------ */
 /* 2. Host interfaces the path keeps.                                   */
 /* ------------------------------------------------------------------ */

@@ -1,0 +1,87 @@
+"""fem_run: the command-line driver over the C-ABI (fem_amd/csrc/fem_run.cpp) that follows the
+reference's main / GPUrun / CPUrun protocol (main.cpp:116-154, 344-617, 619-676).  Run here on
+BASELINE config 1 as the reference would be: the nu=32 sphere from an .off file, 52 partitions."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import fem_amd as fa
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FEM_RUN = os.path.join(ROOT, "fem_amd", "lib", "fem_run")
+
+ROUND = re.compile(r"Round (\d): Sum / Mean error for n: (\S+) / (\S+) and for c: (\S+) / (\S+)\. "
+                   r"Number of errors in total: (\d+)\((\d+)\)")
+
+
+def run(*args, timeout=120):
+    return subprocess.run([FEM_RUN, *args], capture_output=True, text=True, timeout=timeout)
+
+
+def test_usage_without_arguments():
+    assert os.access(FEM_RUN, os.X_OK), "fem_run not built (python __graft_entry__.py)"
+    res = run()
+    assert res.returncode == 2 and "usage: fem_run" in res.stderr
+
+
+def test_missing_file_is_an_error_not_a_crash(tmp_path):
+    res = run(str(tmp_path / "nothing.off"))
+    assert res.returncode == 1 and "nothing.off" in res.stderr
+
+
+@pytest.fixture(scope="module")
+def sphere_off(tmp_path_factory):
+    pts, tri = fa.make_icosphere(32, 0.1)
+    path = str(tmp_path_factory.mktemp("fem_run") / "sphere32.off")
+    fa.off_write(path, pts, tri)
+    return path, len(pts), len(tri)
+
+
+@pytest.mark.gpu
+def test_reference_protocol_on_config1(sphere_off, tmp_path):
+    path, V, F = sphere_off
+    out = str(tmp_path / "pattern.off")
+    res = run(path, "-v", "--iterations", "100", "--out", out)
+    assert res.returncode == 0, res.stdout + res.stderr
+    rounds = {int(m.group(1)): m for m in ROUND.finditer(res.stdout)}
+    assert set(rounds) == {1, 2}, res.stdout
+    for m in rounds.values():
+        assert int(m.group(7)) == V
+        assert float(m.group(3)) < 1e-10 and float(m.group(5)) < 1e-10      # mean |step() - host operators| per vertex
+    m = re.search(r"Time needed for 100 iterations: (\S+) ms with (\d+) threads each and 52 partitions", res.stdout)
+    assert m and float(m.group(1)) > 0, res.stdout
+    best = re.search(r"Best time with 52 partitions is (\S+)!", res.stdout)
+    assert best and float(best.group(1)) > 0
+    pts, tri, rgb = fa.off_read(out)
+    assert len(pts) == V and len(tri) == F and rgb is not None
+    s = rgb[:, 0].astype(int) + rgb[:, 1].astype(int)
+    assert np.all((s == 254) | (s == 255)) and np.array_equal(rgb[:, 1], rgb[:, 2])   # the colour law of formatKernel
+
+
+@pytest.mark.gpu
+def test_debug_flag_checks_only(sphere_off):
+    res = run(sphere_off[0], "-d")
+    assert res.returncode == 0 and "Round 2" in res.stdout
+    assert "Best time" not in res.stdout and "Time:" not in res.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [(), ("--fuse", "0")])
+def test_native_plan_same_protocol(sphere_off, extra):
+    res = run(sphere_off[0], "--native", "-v", "--iterations", "50", "--rows", "400", *extra)
+    assert res.returncode == 0, res.stdout + res.stderr
+    m = ROUND.search(res.stdout)
+    assert m and int(m.group(1)) == 2
+    assert float(m.group(3)) < 2e-7 and float(m.group(5)) < 2e-7             # fp32 state against the fp64 host steps
+    assert re.search(r"Best time with 25 partitions is (\S+)!", res.stdout)
+
+
+@pytest.mark.gpu
+def test_partition_limit_is_reported_like_the_reference(sphere_off):
+    res = run(sphere_off[0], "-n", "4")                                      # 2560 vertices per partition > 1024
+    assert res.returncode == 0
+    assert "Too many nodes or elements per Block" in res.stdout
+    assert "Best time with -1 partitions" in res.stdout
