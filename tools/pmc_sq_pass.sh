@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/pmc_sq_pass.sh TAG WORKLOAD [extra bench args]
+# two SQ counter passes (<= 8 SQ counters each) of the bench's dominant kernel: issue mix and LDS behaviour
+set -o pipefail
+TAG=$1; WL=$2; shift 2
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=gpurun_out/$TAG
+rm -rf $OUT && mkdir -p $OUT
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq1 -- python3 bench.py --workload $WL --steps 40 --no-cpu-baseline "$@" > $OUT/sq1.log 2>&1 || exit 3
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/sq2 -- python3 bench.py --workload $WL --steps 40 --no-cpu-baseline "$@" > $OUT/sq2.log 2>&1 || exit 4
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+for sub in ("sq1", "sq2"):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, sub), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if "tile_step_kernel" in row["Kernel_Name"] or "sell_step_kernel" in row["Kernel_Name"]:
+                a = acc[row["Counter_Name"]]; a[0] += float(row["Counter_Value"]); a[1] += 1
+    for k, (v, n) in sorted(acc.items()):
+        print("%s %-28s per launch %.4g (launches %d)" % (sub, k, v / max(n, 1), n))
+PY
