@@ -107,6 +107,8 @@ struct fem_plan {
   void *tcoef = nullptr;
   // device assembly (FEM_PLAN_DEVICE_ASSEMBLY): connectivity SoA, positions, per-face records, entry tables
   bool can_assemble = false;
+  bool fan_rows = false;            // every row is one fan in order: assemble_row_fan applies
+  bool wide_rows = false;           // some row has more than 6 entries
   fem_uint F = 0, Vg = 0;
   DevBuf<fem_uint> tri0, tri1, tri2, topo, rowg;
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
@@ -131,17 +133,33 @@ template <typename T> static int setPoints(fem_plan *p, const double *pts) {
 
 template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
   typedef typename Vec<T>::t4 T4;
-  fem_uint nb;
+  // Fan-ordered plans: the rows of at most 6 entries go to a kernel of their own (84 VGPRs, 5 waves per
+  // SIMD); wider rows, if the plan has any, to a second launch whose partial maxima land behind the first one's.
+  fem_uint nb, parts = 1;
   if (p->ksteps > 0) {
     nb = p->ntiles;
-    hipLaunchKernelGGL(assemble_rows_tile_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p,
-                       p->tmeta.p, p->tghost.p, p->txinfo.p, p->rowg.p, (T4 *)p->tcoef, (fem_uint)kTileW, p->blockmax);
+    auto launch = [&](auto kern, double *bm) {
+      hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p, p->tmeta.p, p->tghost.p,
+                         p->txinfo.p, p->rowg.p, (T4 *)p->tcoef, (fem_uint)kTileW, bm);
+    };
+    if (!p->fan_rows) launch(assemble_rows_tile_kernel<T, false>, p->blockmax);
+    else {
+      launch(assemble_rows_tile_kernel<T, true, 1>, p->blockmax);
+      if (p->wide_rows) { launch(assemble_rows_tile_kernel<T, true, 2>, p->blockmax + nb); parts = 2; }
+    }
   } else {
     nb = p->nblocks;
-    hipLaunchKernelGGL(assemble_rows_sell_kernel<T>, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p,
-                       p->slice_off.p, p->rowg.p, (T4 *)p->coef, p->nslices, p->V, p->blockmax);
+    auto launch = [&](auto kern, double *bm) {
+      hipLaunchKernelGGL(kern, dim3(nb), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p, p->slice_off.p, p->rowg.p,
+                         (T4 *)p->coef, p->nslices, p->V, bm);
+    };
+    if (!p->fan_rows) launch(assemble_rows_sell_kernel<T, false>, p->blockmax);
+    else {
+      launch(assemble_rows_sell_kernel<T, true, 1>, p->blockmax);
+      if (p->wide_rows) { launch(assemble_rows_sell_kernel<T, true, 2>, p->blockmax + nb); parts = 2; }
+    }
   }
-  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, nb, p->maxedge);
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, parts * nb, p->maxedge);
 }
 
 // per-face records (fem_plan_face_records): not needed by the operator, computed on request
@@ -445,8 +463,11 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   if (!model) { fem_default_model(&dm); model = &dm; }
   if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");
   fem::RowOp op;
-  int rc = shard ? fem::buildRowOp(ordered->mesh, ordered->stats, op, shard->loc2glob.data(), (fem::uint)shard->loc2glob.size())
-                 : fem::buildRowOp(ordered->mesh, ordered->stats, op);
+  // plans that assemble on the device keep their rows in fan order (assemble_row_fan); the others
+  // keep the ascending order their measured kernels were tuned on
+  const bool fan = (flags & FEM_PLAN_DEVICE_ASSEMBLY) != 0;
+  int rc = shard ? fem::buildRowOp(ordered->mesh, ordered->stats, op, shard->loc2glob.data(), (fem::uint)shard->loc2glob.size(), fan)
+                 : fem::buildRowOp(ordered->mesh, ordered->stats, op, nullptr, 0, fan);
   if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh has no topology/stats or is too large");
   fem::SellLayout L;
   fem::TileLayout TL;
@@ -538,6 +559,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   if (e == hipSuccess && (flags & FEM_PLAN_DEVICE_ASSEMBLY)) {
     const fem::SimpleTriMesh &m = ordered->mesh;
     p->F = m.n_faces(); p->Vg = m.n_vertices(); p->can_assemble = true;
+    p->fan_rows = op.fanOrdered && getenv("FEM_ASSEMBLE_GENERIC") == nullptr;
+    for (fem::uint r = 0; r < op.V && !p->wide_rows; r++) p->wide_rows = op.rowptr[r + 1] - op.rowptr[r] > 6;
     std::vector<fem_uint> t0(p->F), t1(p->F), t2(p->F);
     for (fem_uint f = 0; f < p->F; f++) { t0[f] = m.faces[3 * (size_t)f]; t1[f] = m.faces[3 * (size_t)f + 1]; t2[f] = m.faces[3 * (size_t)f + 2]; }
     const std::vector<fem_uint> &topo = ksteps > 0 ? TL.topo : L.topo;
@@ -546,7 +569,7 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     ok(p->rowg.alloc(op.rowg.size())) && ok(p->rowg.upload(op.rowg.data())) &&
     ok(hipMalloc(&p->pos, 4 * sb * p->Vg)) && ok(hipMalloc(&p->pos0, 4 * sb * p->Vg)) &&
     ok(hipMalloc((void **)&p->maxedge, 8)) && ok(hipMemset(p->maxedge, 0, 8)) &&
-    ok(hipMalloc((void **)&p->blockmax, 8 * (size_t)(std::max<size_t>(ksteps > 0 ? TL.ntiles : (L.nslices + 3) / 4, 1))));
+    ok(hipMalloc((void **)&p->blockmax, 2 * 8 * (size_t)(std::max<size_t>(ksteps > 0 ? TL.ntiles : (L.nslices + 3) / 4, 1))));
   }
   if (e == hipSuccess && (flags & FEM_PLAN_IMPLICIT)) {
     // lumped mass a_v and sum_j w_vj of every row (MeshStats: areaPerVtx, -wVtx)

@@ -131,14 +131,17 @@ struct SellLayout {
 // Folded operator in CSR form over local rows (whole mesh, or a shard's loc2glob list).
 struct RowOp {
   uint V = 0;
-  std::vector<uint> rowptr, col;             // [V+1], [nnz] local column ids, ascending global order
+  std::vector<uint> rowptr, col;             // [V+1], [nnz] local column ids: ascending global order, or (fan = true) the
+                                             // counter-clockwise order of the fan around the vertex
+  bool fanOrdered = false;                   // every row is one fan in order: entry k's left face ends at entry k+1 (the
+                                             // last one wraps to entry 0 on a closed fan), its right face at entry k-1
   std::vector<uint> nb;                      // [2*nnz] (mesh id of neighbour j, s1 | s2 << 8 | 1 << 16): s1/s2 = row slots of
                                              // the vertices opposite edge (v, j) in the faces left of v->j / j->v (0xff = none)
   std::vector<uint> rowg;                    // [V] mesh vertex id of each row
   std::vector<double> coef;                  // [4*nnz] (w, Cx, Cy, Cz)
 };
 int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &out, const uint *loc2glob = nullptr,
-               uint nloc = 0);
+               uint nloc = 0, bool fan = false);
 int packSellLayout(const RowOp &op, SellLayout &out);
 
 // Tiles of the fused k-step kernel (pack.cpp).

@@ -148,7 +148,7 @@ __device__ __forceinline__ typename Vec<T>::t4 entry_terms(const T *ej, const T 
     a.x += (f.l2 - f.d) * rcn;                         // cot at o1
     const T s = ang * rcn * rcn;                       // angle * grad phi_j, grad phi_p = e2 x c / |c|^2
     a.y += s * (e1[1] * f.cz - e1[2] * f.cy); a.z += s * (e1[2] * f.cx - e1[0] * f.cz); a.w += s * (e1[0] * f.cy - e1[1] * f.cx);
-    theta += ang; area3 += f.c2 * rcn / 6;             // area / 3 = |c| / 6
+    theta += ang; area3 += f.c2 * rcn * (T)(1.0 / 6.0);   // area / 3 = |c| / 6
   }
   if (has2) {                                          // face (v, o2, j): p = o2, q = j
     const FanFace<T> f = fan_face<T>(e2, ej);
@@ -162,11 +162,20 @@ __device__ __forceinline__ typename Vec<T>::t4 entry_terms(const T *ej, const T 
   return a;
 }
 
+// row normalisation: w = cot sum / (2 lumped mass), C = angle-weighted gradient sum / angle sum; the two
+// reciprocals are taken once per row (a true division per component cost a fifth of the kernel)
+template <typename T> struct RowScale { T inv2a, invTheta; };
 template <typename T>
-__device__ __forceinline__ typename Vec<T>::t4 entry_scale(const typename Vec<T>::t4 &a, T area3, T theta) {
+__device__ __forceinline__ RowScale<T> row_scale(T area3, T theta) {
+  RowScale<T> r;
+  r.inv2a = area3 > 0 ? (T)1 / (2 * area3) : (T)0;
+  r.invTheta = theta > 0 ? (T)1 / theta : (T)0;
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::t4 entry_scale(const typename Vec<T>::t4 &a, const RowScale<T> &r) {
   typename Vec<T>::t4 o;
-  o.x = area3 > 0 ? a.x / (2 * area3) : (T)0;
-  if (theta > 0) { o.y = a.y / theta; o.z = a.z / theta; o.w = a.w / theta; } else { o.y = o.z = o.w = 0; }
+  o.x = a.x * r.inv2a; o.y = a.y * r.invTheta; o.z = a.z * r.invTheta; o.w = a.w * r.invTheta;
   return o;
 }
 
@@ -184,13 +193,19 @@ __device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict_
   const T4 P = pos[vg];
   T area3 = 0, theta = 0, maxe2 = 0;
   if constexpr (W > 0) {
+    // every load unconditional (index clamped, value selected afterwards): a load inside a branch is
+    // followed by a wait at the merge, which turned the 6 + 7 loads of a row into 13 round trips
     uint2 t[W];
 #pragma unroll
-    for (int k = 0; k < W; k++) t[k] = (uint)k < width ? topo[at(k)] : make_uint2(0u, 0xffffu);
+    for (int k = 0; k < W; k++) {
+      const uint2 q = topo[at((uint)k < width ? k : 0)];
+      t[k].x = q.x;                                  // used by the gather in any case: keeps the load out of a branch
+      t[k].y = (uint)k < width ? q.y : 0xffffu;
+    }
     T e[W][3];
 #pragma unroll
     for (int k = 0; k < W; k++) {
-      const T4 J = pos[(t[k].y >> 16) & 1u ? t[k].x : vg];
+      const T4 J = pos[t[k].x];                      // padding entries name vertex 0: loaded, never used
       e[k][0] = J.x - P.x; e[k][1] = J.y - P.y; e[k][2] = J.z - P.z;
     }
     T4 acc[W];
@@ -206,9 +221,10 @@ __device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict_
       }
       acc[k] = entry_terms<T>(e[k], e1, e2, real, real && s1 < (uint)W, real && s2 < (uint)W, area3, theta, maxe2);
     }
+    const RowScale<T> rs = row_scale<T>(area3, theta);
 #pragma unroll
     for (int k = 0; k < W; k++)
-      if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], area3, theta);
+      if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], rs);
   } else {
     for (int k = 0; k < (int)width; k++) {
       const uint2 tk = topo[at(k)];
@@ -220,8 +236,71 @@ __device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict_
       const T e2[3] = {O2.x - P.x, O2.y - P.y, O2.z - P.z};
       coef[at(k)] = entry_terms<T>(ej, e1, e2, real, has1, has2, area3, theta, maxe2);
     }
-    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_scale<T>(coef[at(k)], area3, theta);
+    const RowScale<T> rs = row_scale<T>(area3, theta);
+    for (int k = 0; k < (int)width; k++) coef[at(k)] = entry_scale<T>(coef[at(k)], rs);
   }
+  return dev_sqrt(maxe2);
+}
+
+// The same row when its entries are in fan order (RowOp::fanOrdered: entry k's left face ends at
+// entry k + 1, from the last entry of a closed fan at entry 0): face k = (v, j_k, j_next) is computed
+// ONCE and gives entry k its left-face terms and entry next its right-face terms -- half the faces of
+// assemble_row and no compare-select chains.  Term by term the same expressions in the same order of
+// addition (a + b = b + a exactly), so the result is bit-identical to assemble_row on the same layout.
+template <typename T, int W, int SPLIT = W>
+__device__ __forceinline__ T assemble_row_fan(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
+                                              typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
+                                              uint width, size_t xfirst = 0) {
+  typedef typename Vec<T>::t4 T4;
+  auto at = [&](int k) { return k < SPLIT ? first + k * stride : xfirst + (size_t)(k - SPLIT); };
+  const T4 P = pos[vg];
+  T area3 = 0, theta = 0, maxe2 = 0;
+  uint2 t[W];                                        // loads unconditional, as in assemble_row
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint2 q = topo[at((uint)k < width ? k : 0)];
+    t[k].x = q.x;
+    t[k].y = (uint)k < width ? q.y : 0xffffu;
+  }
+  T e[W][3];
+  T4 acc[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const T4 J = pos[t[k].x];
+    e[k][0] = J.x - P.x; e[k][1] = J.y - P.y; e[k][2] = J.z - P.z;
+    acc[k].x = acc[k].y = acc[k].z = acc[k].w = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint s1 = t[k].y & 0xffu;
+    const bool real = (t[k].y >> 16) & 1u, has1 = real && s1 < (uint)W;
+    const bool wrap = (k + 1 == W) || s1 == 0u;              // the face closes the fan: its far edge is entry 0
+    const int kn = k + 1 < W ? k + 1 : 0;
+    T en[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) en[d] = wrap ? e[0][d] : e[kn][d];
+    if (has1) {                                              // face (v, j_k, j_next): p = j_k, q = j_next
+      const FanFace<T> f = fan_face<T>(e[k], en);
+      const T rcn = dev_rsqrt(f.c2);
+      const T ang = dev_acos(f.d * dev_rsqrt(f.l1 * f.l2));
+      const T s = ang * rcn * rcn;
+      // entry k: cot at j_next, angle * grad phi_p (p = j_k) = e_next x c / |c|^2
+      acc[k].x += (f.l2 - f.d) * rcn;
+      acc[k].y += s * (en[1] * f.cz - en[2] * f.cy); acc[k].z += s * (en[2] * f.cx - en[0] * f.cz); acc[k].w += s * (en[0] * f.cy - en[1] * f.cx);
+      // entry next: cot at j_k, angle * grad phi_q (q = j_next) = c x e_k / |c|^2
+      T4 nx;
+      nx.x = (f.l1 - f.d) * rcn;
+      nx.y = s * (f.cy * e[k][2] - f.cz * e[k][1]); nx.z = s * (f.cz * e[k][0] - f.cx * e[k][2]); nx.w = s * (f.cx * e[k][1] - f.cy * e[k][0]);
+      if (wrap) { acc[0].x += nx.x; acc[0].y += nx.y; acc[0].z += nx.z; acc[0].w += nx.w; }
+      else { acc[kn].x += nx.x; acc[kn].y += nx.y; acc[kn].z += nx.z; acc[kn].w += nx.w; }
+      theta += ang; area3 += f.c2 * rcn * (T)(1.0 / 6.0);
+    }
+    if (real) maxe2 = fmax(maxe2, e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2]);
+  }
+  const RowScale<T> rs = row_scale<T>(area3, theta);
+#pragma unroll
+  for (int k = 0; k < W; k++)
+    if ((uint)k < width) coef[at(k)] = entry_scale<T>(acc[k], rs);
   return dev_sqrt(maxe2);
 }
 
@@ -242,7 +321,9 @@ __device__ __forceinline__ void block_max_256(double m, double *__restrict__ blo
   if (threadIdx.x == 0) blockMax[blockIdx.x] = fmax(fmax(s_part[0], s_part[1]), fmax(s_part[2], s_part[3]));
 }
 
-template <typename T>
+// PART: 0 = every row; 1 = rows of at most 6 entries only (small register footprint: 5 waves per SIMD
+// in flight under the dependent loads slice -> table -> positions); 2 = the wider rows only
+template <typename T, bool FAN, int PART = 0>
 __global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
                                                                  const uint2 *__restrict__ topo, const uint *__restrict__ slice_off,
                                                                  const uint *__restrict__ rowg,
@@ -254,14 +335,22 @@ __global__ __launch_bounds__(256) void assemble_rows_sell_kernel(const typename 
     const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
     const uint row = min(slice * 64 + lane, V - 1);    // rows >= V: padding entries only (flag 0)
     const uint vg = rowg[row];
-    if (width <= 6) me = assemble_row<T, 6>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
-    else if (width <= 12) me = assemble_row<T, 12>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
-    else me = assemble_row<T, 0, (1 << 30)>(pos, topo, coef, vg, (size_t)off + lane, 64, width);   // no split: all entries strided
+    if (width == 0) {
+      // a slice of isolated vertices: no entries
+    } else if (width <= 6) {
+      if constexpr (PART != 2)
+        me = FAN ? assemble_row_fan<T, 6>(pos, topo, coef, vg, (size_t)off + lane, 64, width)
+                 : assemble_row<T, 6>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
+    } else if constexpr (PART != 1) {
+      if (width <= 12) me = FAN ? assemble_row_fan<T, 12>(pos, topo, coef, vg, (size_t)off + lane, 64, width)
+                                : assemble_row<T, 12>(pos, topo, coef, vg, (size_t)off + lane, 64, width);
+      else me = assemble_row<T, 0, (1 << 30)>(pos, topo, coef, vg, (size_t)off + lane, 64, width);   // no split: all entries strided
+    }
   }
   block_max_256((double)me, blockMax);
 }
 
-template <typename T>
+template <typename T, bool FAN, int PART = 0>
 __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename Vec<T>::t4 *__restrict__ pos,
                                                                  const uint2 *__restrict__ topo, const uint *__restrict__ meta,
                                                                  const uint *__restrict__ ghost, const uint *__restrict__ xinfo,
@@ -276,10 +365,16 @@ __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename 
     const uint vg = rowg[r < n0 ? base + r : ghost[goff + (r - n0)]];
     const uint xi = xcnt ? xinfo[xoff + r] : 0u, nx = xi >> 16;
     const size_t first = (size_t)roff + r, xfirst = (size_t)roff + (size_t)W * rpad + (xi & 0xffffu);
-    T e;
-    if (nx == 0) e = assemble_row<T, kTileWDev>(pos, topo, coef, vg, first, rpad, W);
-    else if (nx <= 6) e = assemble_row<T, 12, kTileWDev>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
-    else e = assemble_row_wide<T>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+    T e = 0;
+    if (nx == 0) {
+      if constexpr (PART != 2)
+        e = FAN ? assemble_row_fan<T, kTileWDev>(pos, topo, coef, vg, first, rpad, W)
+                : assemble_row<T, kTileWDev>(pos, topo, coef, vg, first, rpad, W);
+    } else if constexpr (PART != 1) {
+      if (nx <= 6) e = FAN ? assemble_row_fan<T, 12, kTileWDev>(pos, topo, coef, vg, first, rpad, W + nx, xfirst)
+                           : assemble_row<T, 12, kTileWDev>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+      else e = assemble_row_wide<T>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
+    }
     me = fmax(me, e);
   }
   block_max_256((double)me, blockMax);

@@ -98,7 +98,34 @@ int packRefLayout(const SimpleTriMesh &m, const MeshStats &s, int n, const uint 
 // the operator row of global vertex loc2glob[r] with column ids remapped to local ones;
 // neighbours outside the list are dropped (only the outermost ghost ring has any, and its rows
 // are never consumed: DESIGN.md "Multi-GPU").
-int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint *loc2glob, uint nloc) {
+// CSR entries [b, e) of vertex v's outgoing half-edges in counter-clockwise fan order: from the
+// edge with no face on its right (open fan) or the smallest neighbour id (closed fan), each next
+// edge goes to the vertex opposite in the face on the left.  Entries a second fan at the same
+// vertex would add (non-manifold vertex) follow in CSR order; the row then fails the fan check.
+static void fanOrder(const SimpleTriMesh &m, uint v, int H3, std::vector<int> &order, std::vector<char> &used) {
+  const int b = m.rowptr[v], e = m.rowptr[v + 1], n = e - b;
+  order.clear();
+  used.assign((size_t)n, 0);
+  int q = b;
+  for (int c = b; c < e; c++)
+    if (m.opp[m.row_he[c]] >= H3) { q = c; break; }
+  for (int cnt = 0; cnt < n; cnt++) {
+    order.push_back(q);
+    used[(size_t)(q - b)] = 1;
+    const int h = m.row_he[q];
+    if (h >= H3) break;                                       // no face on the left: the open fan ends here
+    const uint o1 = m.faces[SimpleTriMesh::prev_halfedge(h)];
+    int nq = -1;
+    for (int c = b; c < e; c++)
+      if (m.col[c] == o1) { nq = c; break; }
+    if (nq < 0 || used[(size_t)(nq - b)]) break;
+    q = nq;
+  }
+  for (int c = b; c < e; c++)
+    if (!used[(size_t)(c - b)]) order.push_back(c);
+}
+
+int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint *loc2glob, uint nloc, bool fan) {
   const uint Vg = m.n_vertices();
   const int H3 = 3 * (int)m.n_faces();
   if (m.H == 0 || s.precision < 0 || Vg == 0) return FEM_ERR_INVALID;
@@ -132,6 +159,9 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
     }
   };
 
+  std::vector<int> order;
+  std::vector<char> used;
+  bool allFans = fan;
   for (uint row = 0; row < V; row++) {
     const uint v = loc2glob ? loc2glob[row] : row;
     o.rowg[row] = v;
@@ -141,7 +171,9 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
       if (h < H3) theta += s.meshAngle[SimpleTriMesh::prev_halfedge(h)];
     }
     const size_t rowStart = o.col.size();
-    for (int e = m.rowptr[v]; e < m.rowptr[v + 1]; e++) {
+    if (fan) fanOrder(m, v, H3, order, used);
+    for (int ei = 0, ne = m.rowptr[v + 1] - m.rowptr[v]; ei < ne; ei++) {
+      const int e = fan ? order[(size_t)ei] : m.rowptr[v] + ei;
       uint lc = m.col[e];
       if (loc2glob) {
         const int32_t l = glob2loc[m.col[e]];
@@ -186,8 +218,24 @@ int buildRowOp(const SimpleTriMesh &m, const MeshStats &s, RowOp &o, const uint 
             if (o.nb[2 * q] == want[sd]) { slot[sd] = (uint)(q - rowStart); break; }
       o.nb[2 * e + 1] = slot[0] | (slot[1] << 8) | (1u << 16);
     }
+    if (allFans) {
+      // one fan in order: a left face leads to the next entry (or, from the last one, back to entry 0),
+      // and that entry's right face leads back here; as many right faces as left faces
+      const uint n = (uint)(rowEnd - rowStart);
+      uint left = 0, right = 0;
+      for (uint k = 0; k < n && allFans; k++) {
+        const uint w = o.nb[2 * (rowStart + k) + 1], s1 = w & 0xffu, s2 = (w >> 8) & 0xffu;
+        if (s2 != 0xffu) right++;
+        if (s1 == 0xffu) continue;
+        left++;
+        const bool next = s1 == k + 1 && s1 < n, wrap = s1 == 0 && k == n - 1 && k > 0;
+        allFans = (next || wrap) && ((o.nb[2 * (rowStart + s1) + 1] >> 8) & 0xffu) == k;
+      }
+      allFans = allFans && left == right;
+    }
     o.rowptr[row + 1] = (uint)o.col.size();
   }
+  o.fanOrdered = allFans;
   return FEM_OK;
 }
 
