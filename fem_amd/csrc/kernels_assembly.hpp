@@ -246,7 +246,7 @@ __device__ __forceinline__ T assemble_row(const typename Vec<T>::t4 *__restrict_
 // entry k + 1, from the last entry of a closed fan at entry 0): face k = (v, j_k, j_next) is computed
 // ONCE and gives entry k its left-face terms and entry next its right-face terms -- half the faces of
 // assemble_row and no compare-select chains.  Term by term the same expressions in the same order of
-// addition (a + b = b + a exactly), so the result is bit-identical to assemble_row on the same layout.
+// addition (a + b = b + a exactly); the two differ only where the compiler contracts into FMAs differently.
 template <typename T, int W, int SPLIT = W>
 __device__ __forceinline__ T assemble_row_fan(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
                                               typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,

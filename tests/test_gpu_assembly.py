@@ -83,3 +83,43 @@ def test_assembly_requires_flag():
     plan = fa.Plan(case.mesh, fa.PREC_F64)
     with pytest.raises(fa.FemError):
         plan.assemble()
+
+
+@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(12, n), 6), (lambda n: strip_case(n), 3),
+                                         (lambda n: scan_case(16, n), 5)])
+@pytest.mark.parametrize("ksteps", [0, 4])
+def test_fan_and_slot_table_assembly_agree(make, nparts, ksteps, monkeypatch):
+    """the fan-ordered fast path (each face once per row) and the slot-table kernel (both faces of every
+    edge) form the same terms in the same order of addition; the compiler contracts them into FMAs
+    differently, so they agree to a few ulp of each column's scale, not bit for bit"""
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_MIXED)
+    coefs = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("FEM_ASSEMBLE_GENERIC", "1")
+        plan = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps, assemble=True)
+        plan.assemble()
+        coefs.append((plan.coef().copy(), plan.max_edge()))
+    scale = np.abs(coefs[0][0]).max(axis=0)
+    assert (np.abs(coefs[0][0] - coefs[1][0]).max(axis=0) <= 4e-7 * scale).all() and coefs[0][1] == coefs[1][1]
+
+
+def test_non_manifold_vertex_falls_back_to_slot_table():
+    """two tetrahedra that share one vertex: its row is two fans, so the plan cannot use the fan kernel;
+    the operator still matches the host assembly"""
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    pts = np.vstack([tet, -tet[1:] * 0.8])
+    faces = [(0, 2, 1), (0, 1, 3), (0, 3, 2), (1, 2, 3)]
+    remap = {0: 0, 1: 4, 2: 5, 3: 6}
+    tri = np.array(faces + [tuple(remap[v] for v in f) for f in faces], np.uint32)
+    mesh = fa.Mesh(pts, tri)
+    part = mesh.partition(1)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    for ksteps in (0, 2):
+        plan = fa.Plan(om, fa.PREC_F64, part=part, ksteps=ksteps, assemble=True)
+        host = plan.coef().copy()
+        plan.assemble()
+        dev = plan.coef()
+        assert np.abs(dev - host).max() <= 1e-11 * np.abs(host).max()
