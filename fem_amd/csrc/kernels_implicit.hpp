@@ -32,13 +32,20 @@ __global__ __launch_bounds__(256) void imex_apply_kernel(const typename Vec<T>::
     const uint v = slice * 64 + lane, vs = v < V ? v : V - 1;
     const T2 s = x[vs];
     T ln = 0, lc = 0;
-#pragma unroll 2
-    for (uint e = off + lane; e < end; e += 64) {
+    auto entry = [&](uint e) {
       const uint j = __builtin_nontemporal_load(&idx[e]);
       const T w = __builtin_nontemporal_load(&wgt[e]);
       const T2 f = x[j];
       ln += w * (f.x - s.x); lc += w * (f.y - s.y);
+    };
+    uint e = off + lane;                      // as sell_step_kernel: six entries' loads in flight at a time
+#pragma unroll 1
+    for (; e + 5 * 64 < end; e += 6 * 64) {
+#pragma unroll
+      for (uint u = 0; u < 6; u++) entry(e + 64 * u);
     }
+#pragma unroll 2
+    for (; e < end; e += 64) entry(e);
     if (v < V) {
       const T a = mass[v];
       if (mode == 0) {

@@ -158,8 +158,7 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
   const uint vs = v < V ? v : V - 1;
   const T2 s = src[vs];
   T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
-#pragma unroll 2
-  for (uint e = off + lane; e < end; e += 64) {
+  auto entry = [&](uint e) {
     const uint j = NT ? __builtin_nontemporal_load(&idx[e]) : idx[e];     // read-once streams: do not evict the state
     const T4 c = NT ? ntload(&coef[e]) : coef[e];
     const T2 f = src[j];
@@ -167,7 +166,17 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
     lapn += c.x * dn; lapc += c.x * dc;
     gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
     gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+  };
+  // six entries (the common valence) at a time with all their loads in flight before the first use;
+  // the entries of a wider slice beyond a multiple of six two at a time
+  uint e = off + lane;
+#pragma unroll 1
+  for (; e + 5 * 64 < end; e += 6 * 64) {
+#pragma unroll
+    for (uint u = 0; u < 6; u++) entry(e + 64 * u);
   }
+#pragma unroll 2
+  for (; e < end; e += 64) entry(e);
   const T2 o = IMEX ? imex_rhs_update<T>(s, lapc, gnx, gny, gnz, gcx, gcy, gcz, m)
                     : reaction_update<T>(s, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
   if (v < V) dst[v] = o;
