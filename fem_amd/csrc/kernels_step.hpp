@@ -247,11 +247,29 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   // 170 G).  X == 1 (plans without extras, the block never runs): kept at the old place, because
   // that build schedules the regular path 4 % faster than either alternative.
   if (X == 2 && xcnt) {
-    for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
-    for (uint i = t; i < xcnt; i += TPB) {
-      xs_coef[i] = tcoef[W * rpad + i];
-      xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
+    // all loads of the staging in flight before the first LDS write (clamped indices, predicated
+    // writes): rpad <= TPB * R rows, and the extras in passes of 2 * TPB
+    uint xi[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) xi[q] = xinfo[xoff + min(t + TPB * q, rpad - 1)];      // first extra | count << 16 per row
+    for (uint i0 = 0; i0 < xcnt; i0 += 2 * TPB) {
+      T4 xc[2];
+      uint xo[2];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint i = min(i0 + t + TPB * u, xcnt - 1);
+        xc[u] = tcoef[W * rpad + i];
+        xo[u] = xinfo[xoff + rpad + i];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const uint i = i0 + t + TPB * u;
+        if (i < xcnt) { xs_coef[i] = xc[u]; xs_off[i] = xo[u] * (uint)sizeof(T2); }
+      }
     }
+#pragma unroll
+    for (int q = 0; q < R; q++)
+      if (t + TPB * q < rpad) xs_info[t + TPB * q] = xi[q];
   }
   if (PRO >= 1) loadGhostIds(0);
 #pragma unroll
