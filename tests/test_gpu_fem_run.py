@@ -85,3 +85,25 @@ def test_partition_limit_is_reported_like_the_reference(sphere_off):
     assert res.returncode == 0
     assert "Too many nodes or elements per Block" in res.stdout
     assert "Best time with -1 partitions" in res.stdout
+
+
+@pytest.mark.gpu
+def test_ply_input_and_partition_range(tmp_path):
+    """binary PLY in (the format scans ship in), two partition counts tried, best one reported"""
+    pts, tri = fa.make_icosphere(8, 0.1)
+    path = str(tmp_path / "s.ply")
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\nelement vertex %d\nproperty float x\nproperty float y\n"
+                 "property float z\nelement face %d\nproperty list uchar int vertex_indices\nend_header\n"
+                 % (len(pts), len(tri))).encode())
+        f.write(pts.astype("<f4").tobytes())
+        rec = np.empty(len(tri), dtype=[("n", "u1"), ("v", "<i4", 3)])
+        rec["n"], rec["v"] = 3, tri
+        f.write(rec.tobytes())
+    res = run(path, "-n", "3:4", "--iterations", "20")
+    assert res.returncode == 0, res.stdout + res.stderr
+    lines = re.findall(r"Errors: (\d+), Partitions: (\d+), Threads: (\d+), Time: (\S+)", res.stdout)
+    assert [int(l[1]) for l in lines] == [3, 4]
+    best = re.search(r"Best time with (\d+) partitions is (\S+)!", res.stdout)
+    times = {int(l[1]): float(l[3]) for l in lines}
+    assert best and int(best.group(1)) == min(times, key=times.get)
