@@ -229,6 +229,34 @@ def test_gpu_tile_classes():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fuse,krings,overlap", [(0, 4, "1"), (5, 10, "1"), (5, 5, "split")])
+def test_rccl_world_of_one(tmp_path, fuse, krings, overlap, monkeypatch):
+    """the RCCL code path itself on the one GPU a test box has: backend nccl, world size 1.  The shard
+    is the whole mesh (no ghosts), so the all-to-all moves nothing -- but the calls are the real ones:
+    torch tensors over library memory handed to RCCL, the asynchronous work handle, is_completed(),
+    wait() on the compute stream, the barrier with device_ids, every branch of the overlapped schedule"""
+    monkeypatch.setenv("FEM_OVERLAP", overlap)
+    nu, nparts, steps = 16, 8, 23
+    part, (n_ref, c_ref) = reference_run(nu, nparts, steps)
+    res = launch(1, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=krings, steps=steps, precision="f64",
+                 fuse=fuse, pg="nccl")[0]
+    assert int(res["own_begin"]) == 0 and int(res["own_end"]) == len(n_ref)
+    assert rel_l2(res["n"], n_ref) <= 1e-11 and rel_l2(res["c"], c_ref) <= 1e-11
+
+
+@pytest.mark.gpu
+def test_rccl_writes_into_library_memory():
+    """real bytes through RCCL into the state buffer libfem_hip.so owns (the halo exchange's data path),
+    with the rank as its own peer: tests/rccl_selfcopy_worker.py"""
+    _launches[0] += 1
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", str(29500 + (os.getpid() * 16 + _launches[0]) % 2000),
+           os.path.join(ROOT, "tests", "rccl_selfcopy_worker.py")]
+    res = subprocess.run(cmd, timeout=150, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True)
+    assert res.returncode == 0 and "selfcopy ok" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+
+
+@pytest.mark.gpu
 def test_bench_survives_rccl_bringup_failure():
     """bench.py as the driver launches it for N > 1 (backend nccl), but with both ranks on ONE GPU
     (FEM_BENCH_SHARE_GPU=1): RCCL refuses duplicate devices at its first collective, the ranks agree
