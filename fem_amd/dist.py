@@ -160,6 +160,7 @@ class ShardedRun:
         tc = getattr(self.stepper, "tile_classes", None)
         self.classes = tc() if (tc is not None and os.environ.get("FEM_OVERLAP", "1") != "0") else None
         self.force_split = os.environ.get("FEM_OVERLAP", "1") == "split"   # tests: always take the not-yet-arrived path
+        self.force_sync = os.environ.get("FEM_OVERLAP", "1") == "sync"     # tests: blocking exchange, so always the arrived path
         # one exchange up front (re-sends the ghosts' own initial values): brings up the RCCL
         # communicator and its buffers outside any timed region.  `control_group` (a gloo group over
         # the same ranks) makes that bring-up survivable: if RCCL raises here on any rank, all ranks
@@ -231,7 +232,8 @@ class ShardedRun:
                     self._wait_exchange()
             if last:
                 st.launch(nI, nB, s, dt, model, stream)
-                self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=True, host_group=self.host_group)
+                self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=not self.force_sync,
+                                             host_group=self.host_group)
                 self.pending_exchange = True
                 if not first or merged:
                     st.launch(0, nI, s, dt, model, stream)
