@@ -14,13 +14,15 @@ template <typename T> struct ModelT { T nMaxOff, D, r, alpha, S, dt, bn, cden; }
 // The buffers hold deviations (n - bn, c - bn/(1+bn)) from the homogeneous state: differences
 // are unchanged, n(nMax - n) = n((nMax - bn) - dev) and n/(1+n) - c = dev_n/((1+n)(1+bn)) - dev_c
 // are exact rewrites, and the update no longer rounds at the magnitude of n itself.
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ double fast_div(double a, double b) { return a / b; }
 template <typename T>
 __device__ __forceinline__ typename Vec<T>::t2 reaction_update(typename Vec<T>::t2 s, T lapn, T lapc, T gnx, T gny,
                                                                T gnz, T gcx, T gcy, T gcz, const ModelT<T> &m) {
   const T n = m.bn + s.x;
   const T dotP = gnx * gcx + gny * gcy + gnz * gcz;
   const T dauN = m.D * lapn - m.alpha * n * lapc - m.alpha * dotP + m.S * m.r * n * (m.nMaxOff - s.x);
-  const T dauC = lapc + m.S * (s.x * m.cden / (1 + n) - s.y);
+  const T dauC = lapc + m.S * (fast_div(s.x * m.cden, 1 + n) - s.y);
   const T un = m.dt * dauN + s.x, uc = m.dt * dauC + s.y;
   typename Vec<T>::t2 o;
   o.x = un + m.bn > 0 ? un : -m.bn;                 // max(0, n) of FEM_common.cu:164-165
