@@ -321,7 +321,12 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
       const uint r = t + TPB * q;
       if (r < lim) {
         const T2 self = cur[r];
-        T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+        // accumulators paired the way a coefficient record lies in its registers: (w, Cx) and (Cy, Cz)
+        // times dn, the same times dc -- four packed FMAs per entry whose coefficient operands are the
+        // loaded register pairs themselves (any other pairing makes the compiler keep rearranged copies
+        // of all coefficients: + 43 VGPRs)
+        typedef T V2 __attribute__((ext_vector_type(2)));
+        V2 an = {0, 0}, bn = {0, 0}, ac = {0, 0}, bc = {0, 0};       // (lap, gx), (gy, gz) of n and of c
         if constexpr (IXL) {
 #pragma unroll
           for (int w = 0; w < W / 2; w++) ix[q][w] = xs_ix[w * (TPB * R) + r];
@@ -333,11 +338,12 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
           const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);   // byte offset in the buffer
           const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
           const T4 c = cf[q][w];
+          const V2 cxy = {c.x, c.y}, czw = {c.z, c.w};
           const T dn = f.x - self.x, dc = f.y - self.y;
-          lapn += c.x * dn; lapc += c.x * dc;
-          gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
-          gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+          an += cxy * dn; bn += czw * dn;
+          ac += cxy * dc; bc += czw * dc;
         }
+        T lapn = an.x, gnx = an.y, gny = bn.x, gnz = bn.y, lapc = ac.x, gcx = ac.y, gcy = bc.x, gcz = bc.y;
         if (X && xcnt) {                                 // entries W, W+1, ... of a wide row
           const uint xi = xs_info[r];
           for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {
