@@ -210,7 +210,7 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   };
   auto kern = p->maxExtra ? pick(std::integral_constant<int, 2>()) : pick(std::integral_constant<int, 1>());
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
-                     (size_t)TPB * R * 4 * (1 + kTileW / 2);
+                     (size_t)TPB * R * 4 * (1 + (kTileOffsetsInLds ? kTileW / 2 : 0));
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

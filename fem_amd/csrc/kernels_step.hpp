@@ -192,6 +192,16 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // vertex-step drops from 136 B to about (ring ratio * 108 + ghost state/ids + 8)/k B: measured 49 B at
 // k = 4 (620-row partitions) and 45 B at k = 5 (530-row partitions) on the 16M sphere.
 // ---------------------------------------------------------------------------
+// packed column offsets of the register rows: in VGPRs (R * W/2 of them), or parked in LDS and re-read
+// every step.  LDS was the way to stay under 128 VGPRs while the compiler kept rearranged copies of all
+// coefficients; with the accumulators paired along the records (below) the registers are there, and the
+// LDS round trip in front of every row's gathers is not (+1 %).
+constexpr bool kTileOffsetsInLds = false;
+#ifndef FEM_TILE_ROW_FENCE
+#define FEM_TILE_ROW_FENCE 1
+#endif
+constexpr bool kTileRowFence = FEM_TILE_ROW_FENCE != 0;
+
 template <typename T, int TPB, int R, int W, int MINW, int X, int PRO>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   uint *xs_off = reinterpret_cast<uint *>(xs_coef + maxExtra);
   uint *xs_info = xs_off + maxExtra;                             // [T*R] rows of the register tile
   uint *xs_ix = xs_info + TPB * R;                               // X: the packed column offsets live here, not in VGPRs
-  constexpr bool IXL = true;                             // packed column offsets in LDS (frees W/2*R VGPRs)
+  constexpr bool IXL = kTileOffsetsInLds;
   const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // extras of wide rows in this tile (X = 0: never any)
   const uint t = threadIdx.x;
 
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
         }
         nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
       }
-      __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
+      if constexpr (kTileRowFence) __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
     }
     __syncthreads();
     T2 *tmp = cur; cur = nxt; nxt = tmp;

@@ -34,7 +34,7 @@ class _Done:
         return os.environ.get("FEM_REHEARSE_PENDING", "0") != "1"
 
 
-def stub_exchange(stepper, shard, stream=None, group=None, which=0, async_op=False):
+def stub_exchange(stepper, shard, stream=None, group=None, which=0, async_op=False, host_group=None):
     stepper.pack(stream, which)          # the device-side work of an exchange; no bytes leave the GPU
     return _Done()
 
