@@ -186,11 +186,11 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // Fused k-step kernel.  One workgroup per tile (pack.cpp:packTileLayout): the tile's owned rows
 // plus k rings of neighbours are staged in LDS (two ping-pong buffers of m[k] pairs), the
 // operator rows of the first m[k-1] local rows are loaded ONCE into registers (thread t holds rows
-// t, t+TPB, ...: R rows x W entries x (float4 coef + 16-bit local column id)), and the workgroup
+// t, t+TPB, ...: R rows x W entries x (float4 coef + 16-bit local column id); default R = 3), and the workgroup
 // takes up to k time steps before writing its owned rows back: step s recomputes rows
 // [0, m[k-1-s]), whose neighbours [0, m[k-s]) are valid from the step before.  HBM traffic per
-// vertex-step drops from 136 B to about (ring ratio * 108 + ghost state/ids + 8)/k B: measured 49 B at
-// k = 4 (620-row partitions) and 45 B at k = 5 (530-row partitions) on the 16M sphere.
+// vertex-step drops from 136 B to about (ring ratio * 108 + ghost state/ids + 8)/k B: measured 45 B at
+// k = 5 (530-row partitions, R = 2) and 38.5 B at k = 6 (760-row partitions, R = 3) on the 16M sphere.
 // ---------------------------------------------------------------------------
 // packed column offsets of the register rows: in VGPRs (R * W/2 of them), or parked in LDS and re-read
 // every step.  LDS was the way to stay under 128 VGPRs while the compiler kept rearranged copies of all
