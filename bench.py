@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--fuse", type=int, default=None,
                     help="time steps fused per launch (0 = single-step sliced-ELL kernel); default FEM_FUSE_STEPS, "
-                         "else the measured best: 6 on the spheres, 5 on the irregular scanned-like meshes")
+                         "else the measured best: 7 on the spheres, 5 on the irregular scanned-like meshes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only (ranks may share a GPU; halo staged through the host)")
@@ -123,7 +123,7 @@ def main():
 
     wl = WORKLOADS[args.workload] if args.mesh is None else dict(nu=0, verts_per_part=256, scanned=True)
     if args.fuse is None:
-        args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if wl.get("scanned") else "6"))
+        args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if wl.get("scanned") else "7"))
     t_host = time.perf_counter()
     scanned = wl.get("scanned", False)
     if args.mesh is not None:
@@ -136,7 +136,9 @@ def main():
     V_total, n_faces = mesh.V, mesh.F
     dt_rule = "stable" if scanned else "reference"
     # fused tiles: partition size such that a partition + (fuse-1) rings fits the register tile
-    tile_n0 = int(os.environ.get("FEM_TILE_N0", {4: "950", 5: "820" if wl.get("scanned") else "880", 6: "760", 7: "650"}.get(args.fuse, "760")))
+    # (regular meshes get the 2048-row register tile, meshes with rows wider than 6 entries the 1536-row one)
+    tile_n0 = int(os.environ.get("FEM_TILE_N0", ({4: "950", 5: "820", 6: "760", 7: "650"} if wl.get("scanned") else
+                                                 {5: "1200", 6: "1050", 7: "975", 8: "900"}).get(args.fuse, "820")))
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     if world > 1:
         from fem_amd import dist as fdist

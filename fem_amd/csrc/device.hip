@@ -77,9 +77,10 @@ constexpr int kTileW = 6;
 constexpr fem_uint kTileMaxLocal = 4096;
 constexpr fem_uint kTileMaxExtra = 1536;  // LDS-resident overflow entries per tile (rows with more than kTileW neighbours)
 struct TileCfg { int tpb, r, minw; };
-constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}, {1024, 2, 4}, {512, 2, 6}, {768, 2, 6}};
+constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}, {1024, 2, 4}, {512, 2, 6}, {768, 2, 6}, {512, 4, 4}};
 constexpr int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
-constexpr int kDefaultTileCfg = 2;   // 512 threads x 3 register rows: 1536-row tiles, 120 VGPRs, 2 workgroups per CU
+constexpr int kDefaultTileCfg = 8;       // 512 threads x 4 register rows: 2048-row tiles, 128 VGPRs, 2 workgroups per CU
+constexpr int kDefaultTileCfgWide = 2;   // 512 x 3: 1536-row tiles, 120 VGPRs (meshes with rows of more than 6 entries)
 
 
 struct fem_ref_device {
@@ -210,7 +211,7 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   };
   auto kern = p->maxExtra ? pick(std::integral_constant<int, 2>()) : pick(std::integral_constant<int, 1>());
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
-                     (size_t)TPB * R * 4 * (1 + (kTileOffsetsInLds ? kTileW / 2 : 0));
+                     (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -486,7 +487,12 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     if (covered != own_e - own_b) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partitions do not tile the owned range");
     for (fem::uint g = own_e - own_b; g < op.V; g += 512) ranges.push_back(std::make_pair(g, std::min(op.V, g + 512)));
     const char *cfgEnv = getenv("FEM_TILE_CONFIG");
-    tcfg = cfgEnv ? atoi(cfgEnv) : kDefaultTileCfg;
+    // default geometry: 512 threads x 4 register rows (2048-row tiles) when no row is wider than the
+    // register tile's 6 entries; meshes with wide rows also stage extras in LDS, where two workgroups
+    // per CU only fit with the 3-row tile
+    bool wideRows = false;
+    for (fem::uint r = 0; r < op.V && !wideRows; r++) wideRows = op.rowptr[r + 1] - op.rowptr[r] > kTileW;
+    tcfg = cfgEnv ? atoi(cfgEnv) : (wideRows ? kDefaultTileCfgWide : kDefaultTileCfg);
     if (tcfg < 0 || tcfg >= kNumTileCfgs) return fail(FEM_ERR_INVALID, "FEM_TILE_CONFIG out of range");
     rc = fem::packTileLayout(op, ranges, ksteps, kTileCfgs[tcfg].tpb, kTileCfgs[tcfg].r, kTileW,
                              precision == FEM_PREC_F32 ? kTileMaxLocal : kTileMaxLocal * 3 / 4,
@@ -690,7 +696,7 @@ static int launchTiles(fem_plan *p, fem_uint first, fem_uint count, int nsteps, 
     e = p->precision == FEM_PREC_F32 ? launchTile<float, C>(p, first, count, src, dst, nsteps, mf, (hipStream_t)stream) \
                                      : launchTile<double, C>(p, first, count, src, dst, nsteps, md, (hipStream_t)stream); \
     break;
-  switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) FEM_TILE_CASE(5) FEM_TILE_CASE(6) FEM_TILE_CASE(7) }
+  switch (p->tcfg) { FEM_TILE_CASE(0) FEM_TILE_CASE(1) FEM_TILE_CASE(2) FEM_TILE_CASE(3) FEM_TILE_CASE(4) FEM_TILE_CASE(5) FEM_TILE_CASE(6) FEM_TILE_CASE(7) FEM_TILE_CASE(8) }
 #undef FEM_TILE_CASE
   if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "tile_step_kernel launch", e);
   return FEM_OK;

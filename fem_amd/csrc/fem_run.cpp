@@ -29,7 +29,7 @@ struct Options {
   bool debug = false, verbose = false, native = false, hostConstants = false;
   int startN = 52, endN = 52;        // main.cpp:100-101
   int maxIt = 1000;                  // main.cpp:548
-  int fuse = 6, rowsPerPart = 760;   // native plan: fused steps per launch, rows per partition
+  int fuse = 6, rowsPerPart = 820;   // native plan: fused steps per launch, rows per partition
   unsigned seed = 1;
 };
 
@@ -246,7 +246,7 @@ int usage() {
                "  -n               partition counts to try (default 52, the reference's start_n..end_n)\n"
                "  --iterations     timed iterations of two steps each (default 1000)\n"
                "  --native         native fp32 plan instead of step() on the reference layout; partitions of R rows\n"
-               "                   (default 760) unless -n is given, K fused steps per launch (default 6, 0 = one)\n"
+               "                   (default 820) unless -n is given, K fused steps per launch (default 6, 0 = one)\n"
                "  --host-constants r = 1.52, alpha = 12.02 (main.cpp:49-54) instead of the kernel's set; native only\n"
                "  --out            write the coloured result (COFF)\n");
   return 2;

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
 // every step.  LDS was the way to stay under 128 VGPRs while the compiler kept rearranged copies of all
 // coefficients; with the accumulators paired along the records (below) the registers are there, and the
 // LDS round trip in front of every row's gathers is not (+1 %).
-constexpr bool kTileOffsetsInLds = false;
+constexpr bool tileOffsetsInLds(int rowsPerThread) { return rowsPerThread >= 4; }   // 4 rows need the 12 VGPRs back
 #ifndef FEM_TILE_ROW_FENCE
 #define FEM_TILE_ROW_FENCE 1
 #endif
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   uint *xs_off = reinterpret_cast<uint *>(xs_coef + maxExtra);
   uint *xs_info = xs_off + maxExtra;                             // [T*R] rows of the register tile
   uint *xs_ix = xs_info + TPB * R;                               // X: the packed column offsets live here, not in VGPRs
-  constexpr bool IXL = kTileOffsetsInLds;
+  constexpr bool IXL = tileOffsetsInLds(R);
   const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;      // extras of wide rows in this tile (X = 0: never any)
   const uint t = threadIdx.x;
 

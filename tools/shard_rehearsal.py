@@ -22,7 +22,7 @@ rank = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 krings = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 400
 nu = {"sphere16m": 1280, "sphere4m": 640, "sphere1m": 320, "scan8m": 900, "scan500k": 224}[wl]
-fuse = int(os.environ.get("FEM_FUSE_STEPS", "6"))
+fuse = int(os.environ.get("FEM_FUSE_STEPS", "7"))
 
 
 class _Done:
@@ -43,7 +43,7 @@ fdist.exchange_halo = stub_exchange
 pts, tri = fa.make_scanned_like(nu, 0.1, seed=3) if wl.startswith("scan") else fa.make_icosphere(nu, 0.1)
 mesh = fa.Mesh(pts, tri)
 V = mesh.V
-run = fdist.ShardedRun(mesh, max(world, V // int(os.environ.get("FEM_TILE_N0", {4: "950", 5: "880", 6: "760"}.get(fuse, "760")))), rank, world, "f32", krings=krings,
+run = fdist.ShardedRun(mesh, max(world, V // int(os.environ.get("FEM_TILE_N0", {5: "1200", 6: "1050", 7: "975"}.get(fuse, "975")))), rank, world, "f32", krings=krings,
                        ksteps=fuse, dt_rule="stable" if wl.startswith("scan") else "reference")
 del pts, tri, mesh
 stream = torch.cuda.current_stream()
