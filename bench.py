@@ -123,7 +123,7 @@ def main():
 
     wl = WORKLOADS[args.workload] if args.mesh is None else dict(nu=0, verts_per_part=256, scanned=True)
     if args.fuse is None:
-        args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if wl.get("scanned") else "7"))
+        args.fuse = -1                                      # chosen below, once the mesh size is known
     t_host = time.perf_counter()
     scanned = wl.get("scanned", False)
     if args.mesh is not None:
@@ -136,8 +136,12 @@ def main():
     V_total, n_faces = mesh.V, mesh.F
     dt_rule = "stable" if scanned else "reference"
     # fused tiles: partition size such that a partition + (fuse-1) rings fits the register tile
-    # (regular meshes get the 2048-row register tile, meshes with rows wider than 6 entries the 1536-row one)
-    tile_n0 = int(os.environ.get("FEM_TILE_N0", ({4: "950", 5: "820", 6: "760", 7: "650"} if wl.get("scanned") else
+    # (the library gives regular meshes the 2048-row register tile; meshes with rows wider than 6 entries and
+    # plans below 1.5M rows -- kLargeMeshRows in device.hip, per rank -- get the 1536-row one)
+    small = scanned or V_total // world < 1500000
+    if args.fuse < 0:
+        args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if scanned else ("6" if small else "7")))
+    tile_n0 = int(os.environ.get("FEM_TILE_N0", ({4: "950", 5: "820" if scanned else "880", 6: "760", 7: "650"} if small else
                                                  {5: "1200", 6: "1050", 7: "975", 8: "900"}).get(args.fuse, "820")))
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     if world > 1:

@@ -80,6 +80,7 @@ struct TileCfg { int tpb, r, minw; };
 constexpr TileCfg kTileCfgs[] = {{512, 2, 4}, {256, 4, 3}, {512, 3, 4}, {256, 3, 4}, {256, 2, 4}, {1024, 2, 4}, {512, 2, 6}, {768, 2, 6}, {512, 4, 4}};
 constexpr int kNumTileCfgs = sizeof(kTileCfgs) / sizeof(kTileCfgs[0]);
 constexpr int kDefaultTileCfg = 8;       // 512 threads x 4 register rows: 2048-row tiles, 128 VGPRs, 2 workgroups per CU
+constexpr fem_uint kLargeMeshRows = 1500000;
 constexpr int kDefaultTileCfgWide = 2;   // 512 x 3: 1536-row tiles, 120 VGPRs (meshes with rows of more than 6 entries)
 
 
@@ -492,7 +493,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     // per CU only fit with the 3-row tile
     bool wideRows = false;
     for (fem::uint r = 0; r < op.V && !wideRows; r++) wideRows = op.rowptr[r + 1] - op.rowptr[r] > kTileW;
-    tcfg = cfgEnv ? atoi(cfgEnv) : (wideRows ? kDefaultTileCfgWide : kDefaultTileCfg);
+    // (small meshes: the 3-row tile too -- more, smaller tiles fill the 512 workgroup slots better)
+    tcfg = cfgEnv ? atoi(cfgEnv) : (wideRows || op.V < kLargeMeshRows ? kDefaultTileCfgWide : kDefaultTileCfg);
     if (tcfg < 0 || tcfg >= kNumTileCfgs) return fail(FEM_ERR_INVALID, "FEM_TILE_CONFIG out of range");
     rc = fem::packTileLayout(op, ranges, ksteps, kTileCfgs[tcfg].tpb, kTileCfgs[tcfg].r, kTileW,
                              precision == FEM_PREC_F32 ? kTileMaxLocal : kTileMaxLocal * 3 / 4,
