@@ -266,6 +266,29 @@ def test_fused_tile_plan_f64(make, nparts, ksteps, steps):
     assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
 
 
+@pytest.mark.parametrize("cfg", [0, 2, 6, 7, 8])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_every_register_tile_geometry(cfg, prec, monkeypatch):
+    """FEM_TILE_CONFIG: 512 x 2 / x 3 / x 4 register rows (the defaults by mesh), 512 x 2 at three workgroups
+    per CU, 768 x 2 -- on a regular mesh (partitions of 1000 rows: split for the small tiles) and on the
+    irregular one (wide rows: LDS extras), several launches with a short last one"""
+    monkeypatch.setenv("FEM_TILE_CONFIG", str(cfg))
+    for case, steps, ksteps in ((sphere_case(40, 16), 11, 4), (scan_case(24, 8), 9, 4)):
+        case.mesh.init_stats(fa.PREC_F64)
+        st = case.ostats(ol.F64)
+        dt = min(case.dt, stable_dt(st, case.model))
+        plan = fa.Plan(case.mesh, fa.PREC_F64 if prec == "f64" else fa.PREC_F32, part=case.part, ksteps=ksteps)
+        assert plan.tile_info()["threads"] * plan.tile_info()["rows_per_thread"] == {0: 1024, 2: 1536, 6: 1024, 7: 1536, 8: 2048}[cfg]
+        n0 = case.n0.astype(np.float32).astype(np.float64) if prec == "f32" else case.n0
+        c0 = case.c0.astype(np.float32).astype(np.float64) if prec == "f32" else case.c0
+        plan.set_state(n0, c0)
+        plan.run(steps, dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        n_ref, c_ref = st.step(n0, c0, dt, steps, case.model.as_array())
+        tol = TOL_F64 if prec == "f64" else 1e-5
+        assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol
+
+
 def test_fused_tile_plan_f32_matches_single_step_plan():
     """fp32: the fused kernel and the single-step kernel do the same arithmetic per row"""
     case = sphere_case(64, 40)
