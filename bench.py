@@ -69,6 +69,38 @@ def cpu_baseline(seconds_budget=12.0):
                                                                out[1][0] if 1 in out else float("nan"))}
 
 
+def verify_against_oracle(runner, state, total_steps, seed=1):
+    """The check the reference's caller makes after its warm-up steps (GPUrun, main.cpp:492-541: the CPU path run
+    for the same step count, then per-vertex differences) -- outside the timed region: the oracle's all-f64 CPUrun
+    restatement (OpenMP) from the same initial condition on the same ordered mesh for warmup+steps time steps,
+    compared with the state the timed kernel left (downloaded right after the timed region)."""
+    import numpy as np
+    import fem_amd as fa
+    import oracle_lib as ol
+    t0 = time.perf_counter()
+    om = runner.part.ordered
+    topo = ol.Topology(om.V, om.tri)
+    st = ol.Stats(topo, om.points, ol.F64)
+    n0, c0 = fa.initial_condition(om.V, seed)
+    if runner.precision == "f32":        # the fp32 plan starts from the fp32-rounded deviations (fem_plan_set_state)
+        bn, bc = runner.model.nMax, runner.model.nMax / (1.0 + runner.model.nMax)
+        n0 = bn + (n0 - bn).astype(np.float32).astype(np.float64)
+        c0 = bc + (c0 - bc).astype(np.float32).astype(np.float64)
+    threads = ol.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1))
+    n_ref, c_ref = st.step(n0, c0, runner.dt, total_steps, runner.model.as_array())
+    ol.set_threads(1)
+    n, c = state
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    # the departure from the homogeneous state is what the steps compute: report the error relative to it too
+    dev = max(float(np.linalg.norm(n_ref - runner.model.nMax)), 1e-300)
+    return {"rel_l2_n": rel(n, n_ref), "rel_l2_c": rel(c, c_ref), "rel_l2_n_deviation": float(np.linalg.norm(n - n_ref) / dev),
+            "max_abs_n": float(np.abs(n - n_ref).max()), "steps": total_steps, "tolerance": 1e-5 if runner.precision == "f32" else 1e-11,
+            "state_changed": bool(np.abs(n_ref - n0).max() > 0),
+            "oracle": "fo_step_f64 (oracle/, %d threads), same IC and ordered mesh, %.1f s" % (threads, time.perf_counter() - t0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +114,9 @@ def main():
                     help="time steps fused per launch (0 = single-step sliced-ELL kernel); default FEM_FUSE_STEPS, "
                          "else the measured best: 7 on the spheres, 5 on the irregular scanned-like meshes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed run's result (N=1, warmup+steps <= 64)")
+    ap.add_argument("--sustained-steps", type=int, default=1000,
+                    help="N=1: the same kernel timed over this many further steps after the timed region (config.sustained); 0 = off")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only (ranks may share a GPU; halo staged through the host)")
     args = ap.parse_args()
@@ -181,6 +216,22 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
+    final_state, sustained = None, None
+    if world == 1:
+        if not args.no_verify and args.warmup + args.steps <= 64:
+            final_state = runner.plan.get_state()              # what the timed kernel left; checked below, outside all timing
+        if args.sustained_steps > 0 and args.sustained_steps != args.steps:
+            torch.cuda.synchronize()
+            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            tw = time.perf_counter()
+            s0.record(stream)
+            runner.run(args.sustained_steps, stream)
+            s1.record(stream)
+            torch.cuda.synchronize()
+            tw = time.perf_counter() - tw
+            sustained = {"steps": args.sustained_steps, "value": 2.0 * V_total * args.sustained_steps / tw,
+                         "ms_per_step": tw * 1e3 / args.sustained_steps,
+                         "device_ms_per_step": s0.elapsed_time(s1) / args.sustained_steps}
     if world > 1:
         staged = getattr(runner, "host_group", None)
         tmax = torch.tensor([wall, dev_ms], dtype=torch.float64,
@@ -195,7 +246,7 @@ def main():
         kernel_ms = dev_ms / launches                       # average launch duration, device events
         v_per_launch = runner.vertices_per_launch           # owned vertices this rank advances per launch
         achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch * (args.steps / launches) / (kernel_ms * 1e-3) / 1e9
-        traffic = runner.measured_traffic()
+        traffic, traffic_source = runner.measured_traffic()
         out = {
             "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -209,12 +260,14 @@ def main():
                                       if scanned else "class-I geodesic icosphere", wl["nu"], V_total, n_faces, nparts),
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
-                       "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report,
+                       "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report, "sustained": sustained,
                        "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange%s" % (
                            world, "" if getattr(runner, "fallback_reason", None) is None else
                            " STAGED THROUGH THE HOST over gloo (RCCL did not come up: %s)" % runner.fallback_reason)},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("recorded earlier for exactly this configuration (%s), not measured by this run: %s"
+                                            % (runner.traffic_key(), traffic_source)) if traffic else None,
                          "traffic_rate": traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None,
                          "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                          "alg_bytes_per_vertex_step": ALG_BYTES_PER_VERTEX_STEP, "avg_launch_ms": kernel_ms,
@@ -223,6 +276,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if final_state is not None:
+            out["verify"] = verify_against_oracle(runner, final_state, args.warmup + args.steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -59,6 +59,7 @@ lib.fem_free.argtypes = [vp]
 lib.fem_plan_pack_halo.argtypes = [vp, C.c_uint64, vp]
 lib.fem_plan_pack_halo_from.argtypes = [vp, C.c_int, C.c_uint64, vp]
 lib.fem_plan_launch_tiles.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_double, vp, vp]
+lib.fem_plan_format_noalloc.argtypes = [vp, C.c_uint32, C.c_uint64, C.c_uint64, vp]
 lib.fem_plan_coef_count.restype = C.c_uint64
 lib.fem_plan_coef_count.argtypes = [vp]
 for _name in ("fem_mesh_destroy", "fem_ref_layout_destroy", "fem_ref_device_destroy", "fem_plan_destroy",
@@ -450,6 +451,11 @@ class Plan:
         lo, hi = C.c_double(), C.c_double()
         _check(lib.fem_plan_format(self.h, C.c_uint32(V), _ptr(rgba, f64p), _ptr(rgb, u8p), C.byref(lo), C.byref(hi)))
         return rgba, rgb, lo.value, hi.value
+
+    def format_noalloc(self, dev_rgba, dev_minmax=0, nverts=None, stream=None):
+        """fem_plan_format_noalloc: colours into caller-owned device memory, no allocation, async on stream"""
+        _check(lib.fem_plan_format_noalloc(self.h, C.c_uint32(nverts or self.V), C.c_uint64(dev_rgba), C.c_uint64(dev_minmax),
+                                           vp(stream or 0)))
 
     def tile_info(self):
         k, thr, rpt = C.c_int(), C.c_int(), C.c_int()

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -102,6 +103,7 @@ struct fem_plan {
   DevBuf<fem_uint> slice_off, idx, send_idx;
   // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
   int ksteps = 0, tcfg = 0;
+  int prologue = -1, sell_nt = -1;   // FEM_TILE_PROLOGUE / FEM_SELL_NT as read when the plan was created (-1: by operator size)
   fem_uint ntiles = 0, maxLocal = 0, maxExtra = 0;
   fem_uint nInterior = 0, nBoundary = 0, nGhost = 0;   // tile classes of a shard's plan, in this order
   uint64_t tile_rows = 0, tile_entries = 0;
@@ -203,8 +205,7 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   // Read-once streams go around the caches (nontemporal) only when they cannot live in the 256 MiB
   // Infinity Cache anyway: at 1M vertices (operator 230 MB) plain loads keep the operator cached
   // between launches (247 vs 210 G DOF-it/s), from 4M on the nontemporal ones win (230 vs 223 G).
-  static const int proEnv = getenv("FEM_TILE_PROLOGUE") ? atoi(getenv("FEM_TILE_PROLOGUE")) : -1;   // tuning knob
-  const int pro = proEnv >= 0 ? proEnv : (p->tile_bytes > (256ull << 20) ? 3 : 1);
+  const int pro = p->prologue >= 0 ? p->prologue : (p->tile_bytes > (256ull << 20) ? 3 : 1);   // FEM_TILE_PROLOGUE: tuning knob
   auto pick = [&](auto xtag) {
     constexpr int XV = decltype(xtag)::value;
     return pro == 3 ? tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 3> : pro == 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 2>
@@ -535,6 +536,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   fem_plan *p = new fem_plan();
   p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
   p->precision = precision; p->V = op.V;
+  if (const char *e = getenv("FEM_TILE_PROLOGUE")) p->prologue = std::min(3, std::max(0, atoi(e)));
+  if (const char *e = getenv("FEM_SELL_NT")) p->sell_nt = atoi(e) != 0;
   const size_t sb = precision == FEM_PREC_F32 ? sizeof(float) : sizeof(double);
   hipError_t e = hipSuccess;
   auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -750,8 +753,7 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
                        1.0 / (1.0 + p->base_n)};
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
-    static const int ntEnv = getenv("FEM_SELL_NT") ? atoi(getenv("FEM_SELL_NT")) : -1;
-    const bool nt = ntEnv >= 0 ? ntEnv != 0 : fem_plan_operator_bytes(p) > (256ull << 20);   // see launchTile
+    const bool nt = p->sell_nt >= 0 ? p->sell_nt != 0 : fem_plan_operator_bytes(p) > (256ull << 20);   // see launchTile
     if (p->precision == FEM_PREC_F32)
       hipLaunchKernelGGL((nt ? sell_step_kernel<float, true> : sell_step_kernel<float, false>), dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
@@ -891,6 +893,60 @@ int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *r
       }
   if (nmin) *nmin = hmm[0] + p->base_n;     // the buffers hold deviations from base_n
   if (nmax) *nmax = hmm[1] + p->base_n;
+  return FEM_OK;
+}
+
+// ---- result output without allocation ---------------------------------------------------------------
+// fem_plan_format above allocates its partial-extrema buffer, the extrema pair and a staging buffer on every
+// call.  Callers that cannot allocate (HIP graph capture, tight serving loops) get the same three kernels with the
+// partials and the extrema in a file-scope device array and the colours written straight into the caller's
+// device buffer.  The array exists once per GPU (each device holds its own copy at its own address, looked up
+// once per device with that device current); every call on a GPU shares it, so calls that overlap on one GPU race.
+constexpr fem_uint kFormatMaxBlocks = 1024;                        // partial (min, max) pairs
+constexpr fem_uint kFormatNoAllocMaxVerts = 1u << 26;              // 67 108 864 vertices: 256 grid-stride trips of 1024 x 256 threads
+static __device__ __align__(256) double scratch[2 * kFormatMaxBlocks + 2];
+constexpr int kMaxDevices = 64;
+static double *g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mutex;
+
+static int formatScratch(double **out) {
+  int dev = -1;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev < 0 || dev >= kMaxDevices) return fail(FEM_ERR_LIMIT, "fem_plan_format_noalloc: device ordinal beyond 63");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    double *ptr = nullptr;
+    HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch)));      // this device's copy of the array
+    if (!ptr) return fail(FEM_ERR_DEVICE, "fem_plan_format_noalloc: no device address for the scratch array");
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return FEM_OK;
+}
+
+int fem_plan_format_noalloc(fem_plan *p, fem_uint nverts, uint64_t dev_rgba, uint64_t dev_minmax, void *stream) {
+  if (!p || nverts == 0 || nverts > p->V) return fail(FEM_ERR_INVALID, "fem_plan_format_noalloc: bad vertex count");
+  if (nverts > kFormatNoAllocMaxVerts)
+    return fail(FEM_ERR_LIMIT, "fem_plan_format_noalloc: more than 67108864 vertices (the fixed scratch array is sized for that many); use fem_plan_format");
+  if (!dev_rgba || (dev_rgba & 31u)) return fail(FEM_ERR_INVALID, "fem_plan_format_noalloc: dev_rgba must be a 32-byte aligned device buffer of 4 * nverts doubles");
+  if (dev_minmax & 7u) return fail(FEM_ERR_INVALID, "fem_plan_format_noalloc: dev_minmax must be 8-byte aligned");
+  double *ws = nullptr;
+  const int rc = formatScratch(&ws);
+  if (rc != FEM_OK) return rc;
+  double *part = ws, *mm = ws + 2 * kFormatMaxBlocks;
+  const fem_uint V = nverts, nb = std::min<fem_uint>((V + 255) / 256, kFormatMaxBlocks);
+  hipStream_t st = (hipStream_t)stream;
+  double4 *out = (double4 *)dev_rgba;
+  // every block writes its own partial pair and the final kernel reads exactly nb of them: nothing in the array
+  // has to start at zero, whatever the previous call left there
+  if (p->precision == FEM_PREC_F32) hipLaunchKernelGGL(minmax_kernel<float2>, dim3(nb), dim3(256), 0, st, (const float2 *)p->state[p->cur], V, part);
+  else hipLaunchKernelGGL(minmax_kernel<double2>, dim3(nb), dim3(256), 0, st, (const double2 *)p->state[p->cur], V, part);
+  hipLaunchKernelGGL(minmax_final_kernel, dim3(1), dim3(256), 0, st, (const double *)part, nb, mm);
+  if (p->precision == FEM_PREC_F32) hipLaunchKernelGGL(format_kernel<float2>, dim3((V + 255) / 256), dim3(256), 0, st, (const float2 *)p->state[p->cur], V, (const double *)mm, out);
+  else hipLaunchKernelGGL(format_kernel<double2>, dim3((V + 255) / 256), dim3(256), 0, st, (const double2 *)p->state[p->cur], V, (const double *)mm, out);
+  if (dev_minmax)
+    hipLaunchKernelGGL(minmax_export_kernel, dim3(1), dim3(64), 0, st, (const double *)mm, p->base_n, (double *)dev_minmax);
+  HIP_TRY(hipGetLastError());
   return FEM_OK;
 }
 

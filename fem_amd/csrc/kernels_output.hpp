@@ -45,8 +45,16 @@ __global__ __launch_bounds__(256) void format_kernel(const T2 *__restrict__ stat
                                                      double4 *__restrict__ rgba) {
   const uint i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= V) return;
-  const double n = ((double)state[i].x - mm[0]) / (mm[1] - mm[0]);
+  // a uniform field has max == min: the reference divides by zero there (FEM_common.cu:186-193, NaN colours);
+  // here it maps to n^ = 0
+  const double den = mm[1] - mm[0];
+  const double n = den > 0 ? ((double)state[i].x - mm[0]) / den : 0.0;
   rgba[i] = make_double4(n, 1 - n, 1 - n, 1.0);
+}
+
+// extrema of n itself (the buffers hold deviations from base_n) for a caller-owned device pair
+__global__ void minmax_export_kernel(const double *__restrict__ mm, double base_n, double *__restrict__ out) {
+  if (threadIdx.x < 2) out[threadIdx.x] = mm[threadIdx.x] + base_n;
 }
 
 // halo pack: dst[i] = state[send_idx[i]] (8 or 16 B per lane, coalesced stores)

@@ -43,15 +43,25 @@ class SingleRun:
     def run(self, nsteps, stream=None):
         self.plan.run(nsteps, self.dt, self.model, stream.cuda_stream if stream is not None else None)
 
+    def traffic_key(self):
+        """what a PMC pass is valid for: kernel, precision, rows, fused depth, register tile, partition count"""
+        ti = self.plan.tile_info()
+        return "%s:%s:%d:k%d:%dx%d:p%d" % (self.kernel_name, self.precision, self.V, ti["ksteps"], ti["threads"],
+                                            ti["rows_per_thread"], self.part.n)
+
     def measured_traffic(self):
-        """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (None if no
-        pass was recorded for this mesh size)"""
+        """(HBM bytes per launch, source tag) from the rocprofv3 PMC passes committed under profiles/ --
+        recorded on an earlier run of exactly this configuration (traffic_key), not measured by this
+        process; (None, None) if no pass was recorded for it"""
         path = os.path.join(_PROFILES, "traffic.json")
         if not os.path.exists(path):
-            return None
+            return None, None
         with open(path) as f:
             rec = json.load(f)
-        return rec.get("%s:%s:%d" % (self.kernel_name, self.precision, self.V))
+        hit = rec.get(self.traffic_key())
+        if not isinstance(hit, dict):
+            return None, None
+        return hit.get("hbm_bytes_per_launch"), hit.get("source")
 
 
 class _DevView:
@@ -112,7 +122,10 @@ def exchange_halo(stepper, shard, stream=None, group=None, which=0, async_op=Fal
     memory directly and, with async_op, returns a work handle: kernels launched afterwards on the
     compute stream run beside the exchange until handle.wait().  With gloo (CPU tests, several
     ranks sharing one GPU, or `host_group` = the gloo group ShardedRun falls back to when RCCL
-    cannot be brought up) the buffers are staged through the host, synchronously."""
+    cannot be brought up) the buffers are staged through the host, synchronously.
+    Stream order: the pack kernel and the tiles run on `stream` (None = the null stream), while
+    torch.distributed orders a collective -- and a later handle.wait() -- against torch's CURRENT
+    stream; so both are issued with `stream` made current (wait_exchange for the wait)."""
     import torch
     import torch.distributed as dist
     send = stepper.pack(stream, which) if which else stepper.pack(stream)
@@ -127,7 +140,28 @@ def exchange_halo(stepper, shard, stream=None, group=None, which=0, async_op=Fal
         recv.copy_(recv_h)
         torch.cuda.synchronize()
         return None
-    return dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group, async_op=async_op)
+    if not send.is_cuda:
+        return dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group, async_op=async_op)
+    with torch.cuda.stream(_torch_stream(stream)):
+        return dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group, async_op=async_op)
+
+
+def _torch_stream(stream):
+    """the torch stream object the library launches on: `stream`, or the null stream for None"""
+    import torch
+    return stream if stream is not None else torch.cuda.default_stream()
+
+
+def wait_exchange(work, stream=None, on_device=True):
+    """make `stream` (not whatever torch's current stream happens to be) wait for an asynchronous exchange"""
+    if work is None:
+        return
+    if not on_device:
+        work.wait()
+        return
+    import torch
+    with torch.cuda.stream(_torch_stream(stream)):
+        work.wait()
 
 
 class ShardedRun:
@@ -157,6 +191,7 @@ class ShardedRun:
         self.V = om.V
         self.budget = self.krings                                  # ghosts are fresh: k steps allowed
         self.pending, self.pending_exchange = None, False          # exchange in flight (overlapped schedule)
+        self.pending_stream = None                                 # the stream its consumers run on
         tc = getattr(self.stepper, "tile_classes", None)
         self.classes = tc() if (tc is not None and os.environ.get("FEM_OVERLAP", "1") != "0") else None
         self.force_split = os.environ.get("FEM_OVERLAP", "1") == "split"   # tests: always take the not-yet-arrived path
@@ -234,7 +269,7 @@ class ShardedRun:
                 st.launch(nI, nB, s, dt, model, stream)
                 self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=not self.force_sync,
                                              host_group=self.host_group)
-                self.pending_exchange = True
+                self.pending_exchange, self.pending_stream = True, stream
                 if not first or merged:
                     st.launch(0, nI, s, dt, model, stream)
                 self.budget = self.krings
@@ -249,7 +284,7 @@ class ShardedRun:
 
     def _wait_exchange(self):
         if self.pending is not None:
-            self.pending.wait()
+            wait_exchange(self.pending, self.pending_stream, on_device=isinstance(self.stepper, HipShardStepper))
         self.pending, self.pending_exchange = None, False
 
     def get_owned(self):
@@ -257,4 +292,4 @@ class ShardedRun:
         return self.stepper.get_owned()
 
     def measured_traffic(self):
-        return None
+        return None, None

@@ -286,6 +286,18 @@ int fem_plan_download_coef(fem_plan *p, double *out);
  * the extrema of n.  Synchronises.  Pass the result to fem_off_write for a COFF file. */
 int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *rgb, double *nmin,
                     double *nmax);
+/* No counterpart in the reference.  For callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc: fem_plan_format allocates its partial-extrema
+ * buffer, the extrema pair and a staging buffer on every call and synchronises; this variant runs the same three
+ * kernels asynchronously on `stream` with the partials and extrema in a fixed array inside the library (16 400 B per
+ * GPU, held until the process ends) and writes the colours straight into the caller's device memory:
+ *   dev_rgba   device buffer of 4 * nverts doubles (32-byte aligned): RGBA as fem_plan_format's `rgba`;
+ *   dev_minmax device buffer of 2 doubles (min, max of n), or 0.
+ * It calls no hipMalloc/hipFree and no synchronisation.  nverts <= 67 108 864 (FEM_ERR_LIMIT beyond: the array
+ * is sized for that).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
+ * two threads) race; calls ordered on one stream do not.  The first call on a device looks the array's address up
+ * (make it outside a graph capture). */
+int fem_plan_format_noalloc(fem_plan *p, fem_uint nverts, uint64_t dev_rgba, uint64_t dev_minmax, void *stream);
 /* geometry of a tiled plan: fused steps, tile count, largest tile (rows staged in LDS), operator
  * rows loaded per launch (sum over tiles), workgroup size and rows per thread; ksteps = 0 for a
  * sliced-ELL plan.  Any out-pointer may be NULL. */

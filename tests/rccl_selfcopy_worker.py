@@ -42,6 +42,54 @@ for prec, typestr, dtype in ((fa.PREC_F32, "<f4", torch.float32), (fa.PREC_F64, 
     assert np.abs(c[om.V - m:] - (base_c + exp[:, 1])).max() <= 1e-6
     tol = 1e-6 if prec == fa.PREC_F32 else 1e-15
     assert np.abs(n[:om.V - m] - n0[:om.V - m]).max() <= tol        # rows outside the receive window untouched
+
+# Stream order of the exchange (fem_amd/dist.py:exchange_halo / wait_exchange): pack and consumers on a
+# NON-current side stream, the pack delayed behind a long sleep kernel.  RCCL must not read the send buffer
+# before the pack has run, and a consumer on the side stream must not read the ghost rows before the
+# exchange has landed.
+from fem_amd.dist import exchange_halo, wait_exchange  # noqa: E402
+
+
+class _Shard:
+    pass
+
+
+class _Stepper:
+    """pack = delayed copy on the given stream; ghost segment = the last m rows of the plan's state buffer"""
+
+    def __init__(self, plan, V, m, typestr, dtype):
+        self.full = torch.as_tensor(_DevView(plan.state_buffer(0), (V, 2), typestr), device="cuda")
+        self.sendbuf = torch.zeros((m, 2), dtype=dtype, device="cuda")
+        self.src = (torch.arange(2 * m, device="cuda", dtype=dtype).reshape(m, 2) + 3) / 512
+        self.m, self.V = m, V
+
+    def pack(self, stream, which=0):
+        with torch.cuda.stream(stream):
+            torch.cuda._sleep(200_000_000)           # ~0.1 s: the send buffer is still zero while this runs
+            self.sendbuf.copy_(self.src)
+        return self.sendbuf
+
+    def ghost_view(self, which=0):
+        return self.full[self.V - self.m:]
+
+
+plan = fa.Plan(om, fa.PREC_F64)
+plan.set_state(*fa.initial_condition(om.V, 5))
+m = 53
+st, sh = _Stepper(plan, om.V, m, "<f8", torch.float64), _Shard()
+sh.send_counts, sh.recv_counts = [m], [m]
+side = torch.cuda.Stream()
+assert side != torch.cuda.current_stream()
+for async_op in (True, False):
+    st.sendbuf.zero_()
+    st.ghost_view().zero_()
+    torch.cuda.synchronize()
+    work = exchange_halo(st, sh, side, async_op=async_op)
+    wait_exchange(work if async_op else None, side)
+    with torch.cuda.stream(side):
+        got = st.ghost_view().clone()                # a consumer on the side stream
+    torch.cuda.synchronize()
+    assert torch.equal(got, st.src), "exchange on a side stream delivered stale rows (async_op=%s)" % async_op
 print("selfcopy ok")
 dist.barrier(device_ids=[0])
 dist.destroy_process_group()

@@ -453,3 +453,42 @@ def test_edge_cases_isolated_vertices_and_tiny_meshes():
         n, c = dev.get_state()
         n_m, c_m = case.ostats(ol.MIXED).step(case.n0, case.c0, dt, 6, marr)
         assert rel_l2(n, n_m) <= TOL_REF and rel_l2(c, c_m) <= TOL_REF, len(p)
+
+
+# partition sizes bench.py pairs with each fused depth (rows per partition), by register tile
+_TIMED_N0 = {8: {5: 1200, 6: 1050, 7: 975}, 2: {5: 880, 6: 760, 7: 650}}
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("ksteps", [5, 6, 7])
+@pytest.mark.parametrize("cfg", [2, 8])
+def test_timed_configuration_vs_oracle(cfg, ksteps, prec, monkeypatch):
+    """the configuration bench.py times -- fused depth 5/6/7 on the 512 x 3 and 512 x 4 register tiles with
+    the partition sizes the bench pairs with them, and the nontemporal prologue (FEM_TILE_PROLOGUE=3,
+    otherwise only chosen when the operator exceeds the Infinity Cache) forced -- against the f64 oracle,
+    on a regular sphere and on the irregular mesh, over a step count that is not a multiple of the
+    fused depth (two full launches and a 3-step one)"""
+    monkeypatch.setenv("FEM_TILE_CONFIG", str(cfg))
+    monkeypatch.setenv("FEM_TILE_PROLOGUE", "3")
+    from helpers import Case
+    steps = 2 * ksteps + 3
+    n0rows = _TIMED_N0[cfg][ksteps]
+    sp, st_ = fa.make_icosphere(64, 0.1), fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01)
+    for (pts, tri), regular in ((sp, True), (st_, False)):
+        case = Case(pts, tri, max(2, len(pts) // n0rows))
+        case.mesh.init_stats(fa.PREC_F64)
+        st = case.ostats(ol.F64)
+        dt = case.dt if regular else min(case.dt, stable_dt(st, case.model))
+        plan = fa.Plan(case.mesh, fa.PREC_F64 if prec == "f64" else fa.PREC_F32, part=case.part, ksteps=ksteps)
+        info = plan.tile_info()
+        assert info["ksteps"] == ksteps and info["threads"] * info["rows_per_thread"] == {2: 1536, 8: 2048}[cfg]
+        n0, c0 = (case.n0, case.c0) if regular else smooth_ic(case.pts)
+        if prec == "f32":
+            n0, c0 = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+        plan.set_state(n0, c0)
+        plan.run(steps, dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        n_ref, c_ref = st.step(n0, c0, dt, steps, case.model.as_array())
+        tol = TOL_F64 if prec == "f64" else TOL_F32
+        assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol, (regular, rel_l2(n_gpu, n_ref), rel_l2(c_gpu, c_ref))
+        assert not np.array_equal(n_gpu, n0)
