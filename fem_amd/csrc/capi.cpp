@@ -303,6 +303,12 @@ void fem_shard_info(const fem_shard *s, fem_uint *own_begin, fem_uint *own_end, 
   if (n_send) *n_send = (fem_uint)s->s.send_idx.size();
 }
 
+void fem_shard_ranks(const fem_shard *s, int *rank, int *nranks, int *krings) {
+  if (rank) *rank = s->s.rank;
+  if (nranks) *nranks = s->s.nranks;
+  if (krings) *krings = s->s.krings;
+}
+
 void fem_shard_arrays(const fem_shard *s, const fem_uint **loc2glob, const fem_uint **send_idx,
                       const int **send_counts, const int **recv_counts) {
   if (loc2glob) *loc2glob = s->s.loc2glob.data();

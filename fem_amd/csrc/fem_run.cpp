@@ -1,4 +1,4 @@
-// fem_run -- command-line driver over the C-ABI (include/fem_hip.h only; no HIP header, no Python).
+// fem_run -- command-line driver over the C-ABI (include/fem_hip.h, fem_dist.h; no HIP header, no Python).
 //
 // The caller side of the hot path, as the reference has it in src/main.cpp:
 //   main            (main.cpp:116-154)  mesh file [-d], loop over partition counts, "Best time ..."
@@ -17,9 +17,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
+#include "../../include/fem_dist.h"
 #include "../../include/fem_hip.h"
 
 namespace {
@@ -31,6 +36,11 @@ struct Options {
   int maxIt = 1000;                  // main.cpp:548
   int fuse = 6, rowsPerPart = 820;   // native plan: fused steps per launch, rows per partition
   unsigned seed = 1;
+  // --ranks N: the native plan sharded over N ranks (one host thread and, where there are that many, one GPU each),
+  // halo exchange over RCCL (or device-to-device copies inside this process: --transport inproc)
+  int ranks = 0, krings = 0, precision = FEM_PREC_F32;
+  bool inproc = false;
+  std::string dump;                  // raw doubles: n[V] then c[V] of the final state, ordered numbering
 };
 
 struct Run {                         // what initializeData leaves behind
@@ -237,6 +247,133 @@ double nativeRun(int n, const Options &o, const fem_model &model, const Run &r) 
   return usPerStep;
 }
 
+class ThreadBarrier {
+ public:
+  explicit ThreadBarrier(int n) : n_(n) {}
+  void wait() {
+    std::unique_lock<std::mutex> lock(m_);
+    const int gen = gen_;
+    if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); }
+    else cv_.wait(lock, [&] { return gen != gen_; });
+  }
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  int n_, count_ = 0, gen_ = 0;
+};
+
+// The native protocol (two steps, check, 2 x maxIt timed steps) with the mesh sharded along the partition ranges
+// over o.ranks ranks: every rank steps its shard and exchanges boundary state every krings steps (fem_dist_run).
+double shardedRun(int n, const Options &o, const fem_model &model, const Run &r) {
+  const int R = o.ranks;
+  if (n < R) { std::fprintf(stderr, "--ranks %d needs at least that many partitions (have %d)\n", R, n); return -1; }
+  const int krings = o.krings > 0 ? o.krings : std::max(2, 2 * o.fuse);
+  const int ndev = std::max(1, fem_dist_device_count());
+  char uid[128] = {0};
+  fem_dist_world *world = nullptr;
+  if (o.inproc) { if (!ok(fem_dist_world_create(R, &world), "world")) return -1; }
+  else if (fem_dist_rccl_unique_id(uid) != FEM_OK) { std::fprintf(stderr, "RCCL: %s\n", fem_dist_error_detail()); return -1; }
+  std::vector<double> gn(r.V), gc(r.V);
+  std::atomic<int> failed{0};
+  ThreadBarrier bar(R);
+  std::vector<double> rankMs(R, 0.0);
+  std::vector<int> exchanges(R, 0), mergedG(R, 0), splitG(R, 0);
+  std::vector<fem_uint> ghosts(R, 0);
+  int errorsRound2 = 0;
+  std::vector<double> hn, hc;
+  const bool check = r.V <= 4000000;      // CPUrun of a large mesh takes minutes: check up to 4M vertices
+  if (check && !hostRun(r, model, 2, hn, hc)) return -1;
+
+  auto body = [&](int rank) {
+    fem_shard *shard = nullptr;
+    fem_plan *plan = nullptr;
+    fem_dist *dist = nullptr;
+    void *comm = nullptr, *stream = nullptr;
+    auto bail = [&](const char *what, bool distError) {
+      std::fprintf(stderr, "rank %d: %s: %s\n", rank, what, distError ? fem_dist_error_detail() : fem_error_detail());
+      failed = 1;
+    };
+    bool up = false;
+    do {
+      if (fem_dist_set_device(rank % ndev) != FEM_OK) { bail("device", true); break; }
+      if (fem_shard_create(r.ordered, n, r.nodeParts.data(), rank, R, krings, &shard) != FEM_OK) { bail("shard", false); break; }
+      const int rc = o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), shard, o.precision, &model, o.fuse, &plan)
+                                : fem_plan_create_shard(r.ordered, shard, o.precision, &model, &plan);
+      if (rc != FEM_OK) { bail("plan", false); break; }
+      fem_uint ownB = 0, ownE = 0, nLocal = 0, nSend = 0;
+      fem_shard_info(shard, &ownB, &ownE, &nLocal, &nSend);
+      ghosts[rank] = nLocal - (ownE - ownB);
+      const fem_uint *l2g = nullptr;
+      fem_shard_arrays(shard, &l2g, nullptr, nullptr, nullptr);
+      std::vector<double> ln(nLocal), lc(nLocal);
+      for (fem_uint i = 0; i < nLocal; i++) { ln[i] = r.nFn[l2g[i]]; lc[i] = r.cFn[l2g[i]]; }
+      if (fem_plan_set_state(plan, ln.data(), lc.data()) != FEM_OK) { bail("upload", false); break; }
+      if (fem_dist_stream_create(&stream) != FEM_OK) { bail("stream", true); break; }
+      if (!o.inproc && fem_dist_rccl_comm_create(uid, rank, R, &comm) != FEM_OK) { bail("RCCL communicator", true); break; }
+      if (fem_dist_create(plan, shard, comm, world, &dist) != FEM_OK) { bail("fem_dist_create", true); break; }
+      up = true;
+    } while (false);
+    bar.wait();                                        // every rank is set up (or has failed)
+    if (failed) up = false;
+    auto download = [&]() {
+      fem_uint ownB = 0, ownE = 0, nLocal = 0;
+      fem_shard_info(shard, &ownB, &ownE, &nLocal, nullptr);
+      std::vector<double> ln(nLocal), lc(nLocal);
+      if (fem_dist_wait(dist, stream) != FEM_OK || fem_plan_get_state(plan, ln.data(), lc.data()) != FEM_OK) { failed = 1; return; }
+      std::copy(ln.begin(), ln.begin() + (ownE - ownB), gn.begin() + ownB);
+      std::copy(lc.begin(), lc.begin() + (ownE - ownB), gc.begin() + ownB);
+    };
+    if (up) {
+      // two warm-up steps and the check against CPUrun (main.cpp:480-541)
+      if (fem_dist_run(dist, 2, r.dt, &model, stream) != FEM_OK) { bail("step", true); }
+      else download();
+    }
+    bar.wait();
+    if (rank == 0 && !failed && check) errorsRound2 = reportRound(2, gn, gc, hn, hc, o.verbose || o.debug);
+    bar.wait();
+    if (up && !failed && !o.debug) {
+      const double t0 = seconds();
+      if (fem_dist_run(dist, 2 * o.maxIt, r.dt, &model, stream) != FEM_OK || fem_dist_wait(dist, stream) != FEM_OK ||
+          fem_dist_stream_synchronize(stream) != FEM_OK)
+        bail("step", true);
+      rankMs[rank] = (seconds() - t0) * 1e3;
+      fem_dist_stats(dist, &exchanges[rank], &mergedG[rank], &splitG[rank]);
+      if (!failed && (!o.dump.empty() || !o.out.empty())) download();
+    }
+    bar.wait();
+    fem_dist_destroy(dist);
+    fem_dist_rccl_comm_destroy(comm);
+    fem_dist_stream_destroy(stream);
+    fem_plan_destroy(plan);
+    fem_shard_destroy(shard);
+  };
+  std::vector<std::thread> threads;
+  for (int rank = 0; rank < R; rank++) threads.emplace_back(body, rank);
+  for (auto &t : threads) t.join();
+  fem_dist_world_destroy(world);
+  if (failed) return -1;
+  if (o.debug) return 0;
+  const double ms = *std::max_element(rankMs.begin(), rankMs.end()) / 2;     // slowest rank, per maxIt iterations of two steps
+  const double usPerStep = 1000 * ms / o.maxIt;
+  fem_uint ghostMax = *std::max_element(ghosts.begin(), ghosts.end());
+  std::printf("Ranks: %d (%s, %d device%s), ghost rings: %d, exchanges: %d, groups merged/split: %d/%d, ghost rows (max): %u\n", R,
+              o.inproc ? "in-process copies" : "RCCL", ndev, ndev == 1 ? "" : "s", krings, exchanges[0], mergedG[0], splitG[0], ghostMax);
+  if (o.verbose) {
+    std::printf("Time needed for %d iterations: %f ms and %d partitions\n", o.maxIt, ms, n);
+    std::printf("Average time needed per Iteration: %f us\n", usPerStep);
+  } else {
+    std::printf("Errors: %d, Partitions: %d, Threads: %d, Time: %f\n", errorsRound2, n, R, usPerStep);
+  }
+  if (!o.dump.empty()) {
+    FILE *f = std::fopen(o.dump.c_str(), "wb");
+    if (!f || std::fwrite(gn.data(), 8, gn.size(), f) != gn.size() || std::fwrite(gc.data(), 8, gc.size(), f) != gc.size())
+      std::fprintf(stderr, "cannot write %s\n", o.dump.c_str());
+    if (f) std::fclose(f);
+  }
+  if (!o.out.empty()) writePattern(o, r, gn, gc);
+  return usPerStep;
+}
+
 int usage() {
   std::fprintf(stderr,
                "usage: fem_run MESH.off|MESH.ply [-d] [-v] [-n PARTS | -n FIRST:LAST] [--iterations N] [--seed S]\n"
@@ -248,7 +385,11 @@ int usage() {
                "  --native         native fp32 plan instead of step() on the reference layout; partitions of R rows\n"
                "                   (default 820) unless -n is given, K fused steps per launch (default 6, 0 = one)\n"
                "  --host-constants r = 1.52, alpha = 12.02 (main.cpp:49-54) instead of the kernel's set; native only\n"
-               "  --out            write the coloured result (COFF)\n");
+               "  --out            write the coloured result (COFF)\n"
+               "  --ranks N        native plan sharded over N ranks (threads; GPU = rank mod device count), halo exchange over\n"
+               "                   RCCL every --rings K steps (default 2 x fuse); --transport inproc: device-to-device copies\n"
+               "                   inside this process instead (all ranks may share one GPU); --f64: fp64 plans;\n"
+               "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering)\n");
   return 2;
 }
 
@@ -264,7 +405,9 @@ int main(int argc, char **argv) {
     else if (a == "-v") o.verbose = true;
     else if (a == "--native") o.native = true;
     else if (a == "--host-constants") o.hostConstants = true;
-    else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out") {
+    else if (a == "--f64") o.precision = FEM_PREC_F64;
+    else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out" ||
+             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump") {
       const char *v = value();
       if (!v) return usage();
       if (a == "-n") {
@@ -275,13 +418,17 @@ int main(int argc, char **argv) {
       else if (a == "--seed") o.seed = (unsigned)std::strtoul(v, nullptr, 10);
       else if (a == "--fuse") o.fuse = std::atoi(v);
       else if (a == "--rows") o.rowsPerPart = std::atoi(v);
+      else if (a == "--ranks") { o.ranks = std::atoi(v); o.native = true; }
+      else if (a == "--rings") o.krings = std::atoi(v);
+      else if (a == "--transport") { if (!std::strcmp(v, "inproc")) o.inproc = true; else if (std::strcmp(v, "rccl")) return usage(); }
+      else if (a == "--dump") o.dump = v;
       else o.out = v;
     } else if (!a.empty() && a[0] == '-') return usage();
     else if (o.file.empty()) o.file = a;
     else return usage();
   }
   if (o.file.empty() || o.startN < 1 || o.endN < o.startN || o.maxIt < 1 || o.fuse < 0 || o.fuse > 8 || o.rowsPerPart < 1 ||
-      (o.hostConstants && !o.native))
+      (o.hostConstants && !o.native) || o.ranks < 0 || o.ranks > 64 || o.krings < 0)
     return usage();
 
   fem_model model;
@@ -299,7 +446,7 @@ int main(int argc, char **argv) {
   for (int n = o.startN; n <= o.endN; n++) {
     Run r;
     if (!initializeData(original, n, o, model, r)) { fem_mesh_destroy(original); return 1; }
-    const double t = o.native ? nativeRun(n, o, model, r) : gpuRun(n, o, model, r);
+    const double t = o.ranks > 0 ? shardedRun(n, o, model, r) : (o.native ? nativeRun(n, o, model, r) : gpuRun(n, o, model, r));
     if ((bestN == -1 || bestTime > t) && t > 0) { bestN = n; bestTime = t; }
   }
   if (!o.debug) std::printf("Best time with %d partitions is %.1f!\n", bestN, bestTime);

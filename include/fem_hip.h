@@ -344,6 +344,7 @@ int fem_shard_create(const fem_mesh *ordered, int n, const fem_uint *node_parts,
 void fem_shard_destroy(fem_shard *s);
 void fem_shard_info(const fem_shard *s, fem_uint *own_begin, fem_uint *own_end, fem_uint *n_local,
                     fem_uint *n_send);
+void fem_shard_ranks(const fem_shard *s, int *rank, int *nranks, int *krings);
 /* loc2glob[n_local]; send_idx[n_send] = local ids whose state goes out, grouped by
  * destination rank; send_counts/recv_counts[nranks] (all-to-all split sizes, in vertices) */
 void fem_shard_arrays(const fem_shard *s, const fem_uint **loc2glob, const fem_uint **send_idx,

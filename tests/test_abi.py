@@ -12,9 +12,12 @@ import fem_amd as fa
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
+DIST_LIB = os.path.join(ROOT, "fem_amd", "lib", "libfem_dist.so")
+
+
+def declared_symbols(header="fem_hip.h"):
     names = set()
-    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+    for h in [os.path.join(ROOT, "include", header)]:
         text = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
         text = re.sub(r"#.*", "", text)
         for m in re.finditer(r"\b(\w+)\s*\(", text):
@@ -33,9 +36,21 @@ def test_every_declared_symbol_is_exported():
     assert not missing, missing
 
 
+def test_dist_library_exports_its_header():
+    """libfem_dist.so (RCCL halo exchange, include/fem_dist.h): symbol table only -- loading it here would bring a
+    second RCCL into a process that may already hold torch's"""
+    names = declared_symbols("fem_dist.h") - declared_symbols("fem_hip.h")
+    assert "fem_dist_run" in names and "fem_dist_rccl_comm_create" in names and len(names) >= 12
+    exported = set(re.findall(r" T (\w+)", subprocess.run(["nm", "-D", "--defined-only", DIST_LIB], capture_output=True, text=True).stdout))
+    assert not (names - exported), sorted(names - exported)
+    deps = subprocess.run(["ldd", DIST_LIB], capture_output=True, text=True).stdout
+    assert "librccl" in deps and "libfem_hip" in deps and "oracle" not in deps
+    assert "librccl" not in subprocess.run(["ldd", fa.LIB_PATH], capture_output=True, text=True).stdout
+
+
 def test_header_is_plain_c(tmp_path):
     src = tmp_path / "t.c"
-    src.write_text('#include "fem_hip.h"\nint main(void){fem_model m; fem_default_model(&m); return sizeof(fem_double2)==16 && sizeof(fem_float4)==16 ? 0 : 1;}\n')
+    src.write_text('#include "fem_hip.h"\n#include "fem_dist.h"\nint main(void){fem_model m; fem_default_model(&m); return sizeof(fem_double2)==16 && sizeof(fem_float4)==16 ? 0 : 1;}\n')
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(src), "-o",
                            str(tmp_path / "t.o")])
 
