@@ -72,8 +72,9 @@ struct fem_dist {
   std::vector<int> sc, rc;               // vertices to / from each rank
   std::vector<size_t> soff, roff;        // their offsets (vertices) in the send buffer / ghost segment
   void *sendbuf = nullptr;
-  hipStream_t comm = nullptr;
-  hipEvent_t evPacked = nullptr, evDone = nullptr;
+  hipStream_t comm = nullptr, side = nullptr;
+  hipEvent_t evPacked = nullptr, evDone = nullptr, evTop = nullptr, evSide = nullptr;
+  bool sideBusy = false;
   ncclComm_t nccl = nullptr;
   fem_dist_world *world = nullptr;
   int budget = 0;
@@ -146,24 +147,32 @@ int waitExchange(fem_dist *d, hipStream_t stream) {
 int runOverlapped(fem_dist *d, int nsteps, double dt, const fem_model *model, hipStream_t stream) {
   const fem_uint nI = d->nI, nB = d->nB, nG = d->nG;
   fem_plan *p = d->plan;
+  hipStream_t side = d->side;             // high-priority stream of the boundary tiles + pack (null: all on `stream`)
   for (int done = 0; done < nsteps;) {
     const int s = std::min(std::min(d->ksteps, d->budget), nsteps - done);
     const bool first = d->pending, last = d->budget == s;
     bool merged = false;
+    if (side) {
+      HIP_OK(hipEventRecord(d->evTop, stream));                     // everything of the groups before this one
+      if (d->sideBusy) { HIP_OK(hipStreamWaitEvent(stream, d->evSide, 0)); d->sideBusy = false; }   // ... their boundary tiles too
+    }
     if (first) {
       // the exchange has had the previous group's interior launch to finish: if it has, this group is ONE
       // launch (no short boundary launch with its tail); if not, the interior tiles go first
       const bool arrived = d->mode != 2 && hipEventQuery(d->evDone) == hipSuccess;
-      if (arrived) { FEM_TRY(waitExchange(d, stream)); merged = true; d->nMerged++; }
-      else {
-        FEM_TRY(fem_plan_launch_tiles(p, 0, nI, s, dt, model, stream));
-        FEM_TRY(waitExchange(d, stream));
-        d->nSplit++;
-      }
+      if (arrived) { merged = true; d->nMerged++; }
+      else { FEM_TRY(fem_plan_launch_tiles(p, 0, nI, s, dt, model, stream)); d->nSplit++; }
+      if (side && last) HIP_OK(hipStreamWaitEvent(side, d->evDone, 0));   // the boundary tiles read the ghost rows too
+      FEM_TRY(waitExchange(d, stream));
     }
     if (last) {
-      FEM_TRY(fem_plan_launch_tiles(p, nI, nB, s, dt, model, stream));
-      FEM_TRY(startExchange(d, 1, stream));
+      // boundary tiles, pack and exchange on the side stream, the interior tiles of the same group at once on
+      // `stream`: the two launches share the chip instead of a short launch with its tail in front of a long one
+      hipStream_t bs = side ? side : stream;
+      if (side) HIP_OK(hipStreamWaitEvent(side, d->evTop, 0));
+      FEM_TRY(fem_plan_launch_tiles(p, nI, nB, s, dt, model, bs));
+      FEM_TRY(startExchange(d, 1, bs));
+      if (side) { HIP_OK(hipEventRecord(d->evSide, side)); d->sideBusy = true; }
       if (d->mode == 3) HIP_OK(hipEventSynchronize(d->evDone));
       if (!first || merged) FEM_TRY(fem_plan_launch_tiles(p, 0, nI, s, dt, model, stream));
       d->budget = d->krings;
@@ -175,6 +184,7 @@ int runOverlapped(fem_dist *d, int nsteps, double dt, const fem_model *model, hi
     FEM_TRY(fem_plan_flip(p));
     done += s;
   }
+  if (side && d->sideBusy) { HIP_OK(hipStreamWaitEvent(stream, d->evSide, 0)); d->sideBusy = false; }   // `stream` ends behind everything issued
   return FEM_OK;
 }
 
@@ -258,6 +268,9 @@ void fem_dist_destroy(fem_dist *d) {
   if (!d) return;
   if (d->world && d->world->ranks[d->rank] == d) d->world->ranks[d->rank] = nullptr;
   if (d->comm) { (void)hipStreamSynchronize(d->comm); (void)hipStreamDestroy(d->comm); }
+  if (d->side) { (void)hipStreamSynchronize(d->side); (void)hipStreamDestroy(d->side); }
+  if (d->evTop) (void)hipEventDestroy(d->evTop);
+  if (d->evSide) (void)hipEventDestroy(d->evSide);
   if (d->evPacked) (void)hipEventDestroy(d->evPacked);
   if (d->evDone) (void)hipEventDestroy(d->evDone);
   if (d->sendbuf) (void)hipFree(d->sendbuf);
@@ -314,6 +327,14 @@ int fem_dist_create(fem_plan *plan, const fem_shard *shard, void *comm, fem_dist
   hipError_t e = hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evPacked, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming);
+  const char *bsEnv = getenv("FEM_BOUNDARY_STREAM");
+  if (e == hipSuccess && d->classes && !(bsEnv && !strcmp(bsEnv, "0"))) {
+    int lo = 0, hi = 0;
+    e = hipDeviceGetStreamPriorityRange(&lo, &hi);        // hi = the numerically lowest value = greatest priority
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evTop, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evSide, hipEventDisableTiming);
+  }
   if (e == hipSuccess) e = hipMalloc(&d->sendbuf, std::max<size_t>(1, d->nSend) * pairBytes(d));
   if (e != hipSuccess) {
     fem_dist_destroy(d);

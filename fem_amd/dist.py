@@ -246,30 +246,46 @@ class ShardedRun:
         uses up the ghost budget runs the boundary tiles first, packs and starts the exchange, and
         lets the interior tiles run beside it; the ghost tiles are skipped there (the exchange
         overwrites them).  The first group after an exchange runs the interior tiles (they read
-        no ghost row) before it waits for the exchange."""
+        no ghost row) before it waits for the exchange.
+        On the GPU the boundary tiles, the pack and the exchange go to a high-priority side stream
+        and the interior tiles of the same group are launched on `stream` at once: the two launches
+        share the chip (the few boundary workgroups are dispatched first, the interior ones fill the
+        other slots) instead of a short boundary launch with its tail in front of the interior one."""
         nI, nB, nG = self.classes
         st, dt, model = self.stepper, self.dt, self.model
+        side = self._side_stream(stream)
         done = 0
         while done < nsteps:
             s = min(self.ksteps, self.budget, nsteps - done)
             first, last = self.pending_exchange, self.budget == s
             merged = False
+            if side is not None:
+                self._ev_top.record(stream)                  # everything of the groups before this one
+                if self._side_busy:
+                    stream.wait_event(self._ev_side)         # ... including their boundary tiles
+                    self._side_busy = False
             if first:
                 # the exchange has had the previous group's interior launch to finish: if it has,
                 # this group is ONE launch (no short boundary launch with its tail); if not, the
                 # interior tiles go first and the wait comes after them
                 arrived = self.pending is None or getattr(self.pending, "is_completed", lambda: False)()
                 if not self.force_split and arrived:
-                    self._wait_exchange()
+                    self._wait_exchange(also=side if last else None)
                     merged = True
                 else:
                     st.launch(0, nI, s, dt, model, stream)
-                    self._wait_exchange()
+                    self._wait_exchange(also=side if last else None)
             if last:
-                st.launch(nI, nB, s, dt, model, stream)
-                self.pending = exchange_halo(st, self.shard, stream, which=1, async_op=not self.force_sync,
+                bs = side if side is not None else stream
+                if side is not None:
+                    side.wait_event(self._ev_top)
+                st.launch(nI, nB, s, dt, model, bs)
+                self.pending = exchange_halo(st, self.shard, bs, which=1, async_op=not self.force_sync,
                                              host_group=self.host_group)
                 self.pending_exchange, self.pending_stream = True, stream
+                if side is not None:
+                    self._ev_side.record(side)
+                    self._side_busy = True
                 if not first or merged:
                     st.launch(0, nI, s, dt, model, stream)
                 self.budget = self.krings
@@ -281,10 +297,29 @@ class ShardedRun:
                 self.budget -= s
             st.flip()
             done += s
+        if side is not None and self._side_busy:             # leave `stream` ordered behind everything issued
+            stream.wait_event(self._ev_side)
+            self._side_busy = False
 
-    def _wait_exchange(self):
+    def _side_stream(self, stream):
+        """high-priority stream for the boundary tiles + pack + exchange of a group (None: CPU steppers,
+        the null stream, FEM_BOUNDARY_STREAM=0)"""
+        if stream is None or not isinstance(self.stepper, HipShardStepper) or os.environ.get("FEM_BOUNDARY_STREAM", "1") == "0":
+            return None
+        if getattr(self, "_side", None) is None:
+            import torch
+            self._side = torch.cuda.Stream(priority=-1)
+            self._ev_top, self._ev_side = torch.cuda.Event(), torch.cuda.Event()
+            self._side_busy = False
+        return self._side
+
+    def _wait_exchange(self, also=None):
+        """`also`: a second stream whose next work reads the ghost rows too (the boundary tiles' side stream)"""
         if self.pending is not None:
-            wait_exchange(self.pending, self.pending_stream, on_device=isinstance(self.stepper, HipShardStepper))
+            on_device = isinstance(self.stepper, HipShardStepper)
+            wait_exchange(self.pending, self.pending_stream, on_device=on_device)
+            if also is not None:
+                wait_exchange(self.pending, also, on_device=on_device)
         self.pending, self.pending_exchange = None, False
 
     def get_owned(self):
