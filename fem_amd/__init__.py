@@ -205,6 +205,12 @@ class Mesh:
         self.precision = precision
         return self
 
+    def init_stats_shard(self, precision, shard):
+        """assembly restricted to the rows of a shard's local vertices (fem_mesh_init_stats_shard)"""
+        _check(lib.fem_mesh_init_stats_shard(self.h, C.c_int(precision), shard.h))
+        self.precision = precision
+        return self
+
     def stats(self):
         ps = [f64p() for _ in range(8)]
         mx = C.c_double()

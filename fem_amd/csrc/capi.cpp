@@ -206,6 +206,15 @@ int fem_mesh_init_stats(fem_mesh *m, int precision) {
   return FEM_OK;
 }
 
+int fem_mesh_init_stats_shard(fem_mesh *m, int precision, const fem_shard *shard) {
+  if (!m || !shard || (precision != FEM_PREC_MIXED && precision != FEM_PREC_F64))
+    return fail(FEM_ERR_INVALID, "fem_mesh_init_stats_shard: bad argument");
+  for (fem::uint v : shard->s.loc2glob)
+    if (v >= m->mesh.n_vertices()) return fail(FEM_ERR_INVALID, "fem_mesh_init_stats_shard: the shard is not a shard of this mesh");
+  fem::initMeshStatsRows(m->mesh, m->stats, precision, shard->s.loc2glob);
+  return FEM_OK;
+}
+
 int fem_mesh_stats(const fem_mesh *m, const double **meshAngle, const double **meshCot,
                    const double **meshArea, const double **areaPerVtx, const double **wHej,
                    const double **wVtx, double *maxEdgeLen, const double **gradVec12,

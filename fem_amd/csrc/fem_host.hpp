@@ -71,6 +71,8 @@ struct MeshStats {
 };
 
 void initMeshStats(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision = FEM_PREC_MIXED);
+// the same for the operator rows of the listed vertices only (a shard's local rows): entries no listed row needs stay 0
+void initMeshStatsRows(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision, const std::vector<uint> &rows);
 void deleteMeshStats(MeshStats &mStats);
 
 bool computeLaplacianCPU(const SimpleTriMesh &m, const double *fn, double *lap,

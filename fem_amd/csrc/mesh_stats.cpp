@@ -27,13 +27,25 @@ template <typename G> struct Vec3 {
   G norm() const { return std::sqrt(dot(*this)); }
 };
 
-template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
+// `rows` (optional): assemble only what the operator rows of these vertices need -- the faces around them and
+// the half-edges leaving them; every other entry stays 0.  The sums of a listed vertex run over the same terms
+// in the same order as in the full assembly, so its row is bit-identical.  maxEdgeLen is always global.
+template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s, const std::vector<uint> *rows = nullptr) {
   const int V = (int)m.n_vertices(), F = (int)m.n_faces(), H = m.H, H3 = 3 * F;
   const double *P = m.points.data();
   s.meshAngle.assign(H, 0.0); s.meshCot.assign(H, 0.0);
   s.meshArea.assign(F, 0.0); s.areaPerVtx.assign(V, 0.0);
   s.wHej.assign(H, 0.0); s.wVtx.assign(V, 0.0);
   s.gradVec12.assign(3 * (size_t)F, 0.0); s.gradVec13.assign(3 * (size_t)F, 0.0);
+  std::vector<uint8_t> vNeed, fNeed;
+  if (rows) {
+    vNeed.assign(V, 0); fNeed.assign(F, 0);
+    for (uint v : *rows) vNeed[v] = 1;
+    parallelFor((size_t)F, 300000, [&](size_t fb, size_t fe) {
+      for (size_t f = fb; f < fe; f++) fNeed[f] = vNeed[m.faces[3 * f]] | vNeed[m.faces[3 * f + 1]] | vNeed[m.faces[3 * f + 2]];
+    });
+  }
+  const bool all = rows == nullptr;
 
   // per face: the three corner angles (angle at the to-vertex of each of its
   // half-edges), cotangents, area, hat-function gradients.  Faces write only their own slots, so
@@ -41,6 +53,7 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
   // sums whatever the thread count).
   parallelFor((size_t)F, 100000, [&](size_t fb, size_t fe) {
   for (int f = (int)fb; f < (int)fe; f++) {
+    if (!all && !fNeed[f]) continue;
     const uint ia = m.faces[3 * f], ib = m.faces[3 * f + 1], ic = m.faces[3 * f + 2];
     const Vec3<G> pa(P + 3 * ia), pb(P + 3 * ib), pc(P + 3 * ic);
     const Vec3<G> corner[3] = {pa, pb, pc};
@@ -73,6 +86,7 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
   }
   });
   for (int f = 0; f < F; f++) {                         // lumped mass, in face order (mesh_function.cpp:205-209)
+    if (!all && !fNeed[f]) continue;
     const double a3 = s.meshArea[f] / 3;
     s.areaPerVtx[m.faces[3 * f + 2]] += a3; s.areaPerVtx[m.faces[3 * f]] += a3; s.areaPerVtx[m.faces[3 * f + 1]] += a3;
   }
@@ -80,6 +94,7 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
   // cot-Laplacian rows scaled by the inverse lumped mass
   parallelFor((size_t)H, 300000, [&](size_t hb, size_t he) {
     for (int h = (int)hb; h < (int)he; h++) {
+      if (!all && !vNeed[m.he_from[h]]) continue;
       const int ho = m.opp[h];
       double wg = 0;
       if (h < H3) wg += s.meshCot[SimpleTriMesh::next_halfedge(h)];
@@ -87,7 +102,8 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s) {
       s.wHej[h] = wg / (2 * s.areaPerVtx[m.he_from[h]]);
     }
   });
-  for (int h = 0; h < H; h++) s.wVtx[m.he_from[h]] -= s.wHej[h];     // in half-edge order
+  for (int h = 0; h < H; h++)                                         // in half-edge order
+    if (all || vNeed[m.he_from[h]]) s.wVtx[m.he_from[h]] -= s.wHej[h];
 
   std::vector<double> part((size_t)hostThreads() + 1, 0.0);
   std::atomic<int> slot(0);
@@ -111,6 +127,13 @@ void initMeshStats(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision) {
   mStats.precision = precision;
   if (precision == FEM_PREC_F64) assemble<double>(ipMesh, mStats);
   else assemble<float>(ipMesh, mStats);
+}
+
+void initMeshStatsRows(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision, const std::vector<uint> &rows) {
+  if (ipMesh.H == 0) ipMesh.update_topology();
+  mStats.precision = precision;
+  if (precision == FEM_PREC_F64) assemble<double>(ipMesh, mStats, &rows);
+  else assemble<float>(ipMesh, mStats, &rows);
 }
 
 void deleteMeshStats(MeshStats &mStats) { mStats = MeshStats(); }

@@ -172,14 +172,16 @@ class ShardedRun:
         self.ksteps = ksteps
         self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
         self.steps_per_launch = max(1, ksteps)
+        # the partition is shared (deterministic: every rank computes the same one); everything after it is
+        # rank-local: the shard, then the assembly of the rows of the shard's local vertices only
         self.part = mesh.partition(nparts)
         om = self.part.ordered
-        om.init_stats(fa.PREC_F64)
         self.model = fa.default_model()
-        self.dt = _time_step(om, self.model, dt_rule)
         self.precision = precision
         self.krings = krings or int(os.environ.get("FEM_HALO_RINGS", str(2 * ksteps if ksteps > 0 else 8)))   # two fused launches per exchange
         self.shard = fa.Shard(self.part, rank, world, self.krings)
+        om.init_stats_shard(fa.PREC_F64, self.shard)
+        self.dt = self._time_step(om, dt_rule, world, control_group)
         n0, c0 = fa.initial_condition(om.V, seed)                 # ordered numbering, identical on all ranks
         l2g = self.shard.loc2glob
         if make_stepper is None:
@@ -227,6 +229,23 @@ class ShardedRun:
         sb = 4 if precision == "f32" else 8
         plan = self.plan
         self.layout_bytes_per_launch = (plan.operator_bytes() + 4 * sb * self.shard.n_local) if plan else None
+
+    def _time_step(self, om, rule, world, control_group=None):
+        """_time_step on rank-local stats: maxEdgeLen is the whole mesh's on every rank; the "stable" rule needs the
+        largest |wVtx| of the whole mesh = the maximum over the ranks' owned rows (one all-reduce at set-up)"""
+        st = om.stats()
+        if rule != "stable":
+            return 0.1 * st["maxEdgeLen"] ** 2
+        wmax = float(np.abs(st["wVtx"][self.shard.own_begin:self.shard.own_end]).max())
+        import torch.distributed as dist
+        if world > 1 and dist.is_available() and dist.is_initialized():
+            import torch
+            # over the gloo control group when there is one: RCCL may not be up yet (see the priming exchange)
+            dev = "cuda" if control_group is None and dist.get_backend() == "nccl" else "cpu"
+            t = torch.tensor([wmax], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=control_group)
+            wmax = float(t.item())
+        return 0.2 / (max(1.0, self.model.D) * wmax)
 
     def run(self, nsteps, stream=None):
         if self.classes is not None:

@@ -349,6 +349,11 @@ void fem_shard_ranks(const fem_shard *s, int *rank, int *nranks, int *krings);
  * destination rank; send_counts/recv_counts[nranks] (all-to-all split sizes, in vertices) */
 void fem_shard_arrays(const fem_shard *s, const fem_uint **loc2glob, const fem_uint **send_idx,
                       const int **send_counts, const int **recv_counts);
+/* initMeshStats (mesh_function.cpp:27-67) for one rank: assembles only what the operator rows of the shard's local
+ * vertices (owned + ghost rings) need -- the faces around them, the half-edges leaving them; all other entries of
+ * the arrays fem_mesh_stats returns are 0, maxEdgeLen is the whole mesh's.  A listed row is bit-identical to the full
+ * assembly's.  Plans of that shard can then be created without any rank assembling the whole mesh. */
+int fem_mesh_init_stats_shard(fem_mesh *m, int precision, const fem_shard *shard);
 /* Plan over a shard's local vertices; state arrays are n_local long, ghosts included. */
 int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int precision,
                           const fem_model *model, fem_plan **out);
