@@ -7,6 +7,7 @@ steps, then back-to-back launches with no host sync inside, device-event timed).
 
   python bench.py --gpus 1 --steps K --warmup W [--workload sphere16m|sphere4m|sphere1m|sphere10k|scan8m|scan500k]
                   [--fuse k] [--mesh FILE.off|.ply [--subdivide L]]
+  python bench.py --workload deform4m [--unfused]      config 5: re-assembly on the device every step
 
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
 """
@@ -30,7 +31,12 @@ WORKLOADS = {                       # class-I geodesic spheres, edge ~ 0.1 (BASE
     # 3..16, local high-valence fans, radial noise; 8.1M vertices
     "scan8m": dict(nu=900, verts_per_part=256, scanned=True),
     "scan500k": dict(nu=224, verts_per_part=256, scanned=True),
+    # config 5: deforming mesh, the operator re-assembled on the device every time step (one iteration =
+    # deform kernel + fused assembly-and-step kernel); N = 1 only
+    "deform4m": dict(nu=640, verts_per_part=256, deform=True),
+    "deform250k": dict(nu=160, verts_per_part=256, deform=True),
 }
+ALG_BYTES_PER_ELEMENT_ASSEMBLY = 68  # 54 B per element + 14 B of per-vertex output
 ALG_BYTES_PER_VERTEX_STEP = 168     # V*24 + nnz*8 + F*48 on a closed genus-0 mesh
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -67,6 +73,65 @@ def cpu_baseline(seconds_budget=12.0):
             "sample": "oracle fo_step_f64 (C port of CPUrun, OpenMP), nu=320 icosphere V=%d, %d steps in %.1f s on %d "
                       "thread(s); 1 thread: %.3g DOF-it/s" % (topo.V, out[best][1], out[best][2], best,
                                                                out[1][0] if 1 in out else float("nan"))}
+
+
+def cpu_baseline_deform(seconds_budget=12.0):
+    """config 5 on the host: the oracle's assembly (fo_assemble_f64, serial C restatement of initMeshStats) of a
+    freshly deformed nu=320 sphere + one fo_step_f64 per iteration, as many iterations as fit the budget"""
+    import numpy as np
+    import fem_amd as fa
+    import oracle_lib as ol
+    pts, tri = fa.make_icosphere(320, 0.1)
+    topo = ol.Topology(len(pts), tri)
+    n, c = ol.initial_condition(topo.V, 1)
+    model = fa.default_model().as_array()
+    threads = ol.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 2 or (time.perf_counter() - t0 < seconds_budget and iters < 50):
+        s = 1 + 0.01 * np.sin(1.5708 * pts[:, 0] + 0.01 * iters) * np.cos(1.5708 * pts[:, 1] - 0.005 * iters) * np.sin(1.5708 * pts[:, 2] + 0.0025 * iters)
+        st = ol.Stats(topo, pts * s[:, None], ol.F64)
+        n, c = st.step(n, c, 0.08 * st.maxEdgeLen ** 2, 1, model)
+        iters += 1
+    el = time.perf_counter() - t0
+    ol.set_threads(1)
+    return {"value": 2.0 * topo.V * iters / el, "unit": "DOF-iterations/s", "cores": threads, "kind": "port",
+            "elements_per_s": topo.F * iters / el,
+            "sample": "oracle fo_assemble_f64 (serial) + fo_step_f64 (OpenMP, %d threads) per iteration on a re-deformed nu=320 "
+                      "icosphere V=%d, %d iterations in %.1f s" % (threads, topo.V, iters, el)}
+
+
+def verify_deform(runner, state, total_steps):
+    """config 5: the oracle deforms the ordered mesh with the same law, re-assembles it on the CPU (mixed precision =
+    the reference's Vec3f geometry for the fp32 plan) and steps, every iteration; compared with the state the
+    device loop left.  Tolerance 2e-5 (fp32 geometry round-off), 1e-11 for fp64."""
+    import numpy as np
+    import fem_amd as fa
+    import oracle_lib as ol
+    t0 = time.perf_counter()
+    om = runner.part.ordered
+    pts = om.points
+    topo = ol.Topology(om.V, om.tri)
+    n, c = fa.initial_condition(om.V, runner.seed)
+    f32 = runner.precision == "f32"
+    if f32:
+        bn, bc = runner.model.nMax, runner.model.nMax / (1.0 + runner.model.nMax)
+        n = bn + (n - bn).astype(np.float32).astype(np.float64)
+        c = bc + (c - bc).astype(np.float32).astype(np.float64)
+    threads = ol.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1))
+    for i in range(total_steps):
+        ph = runner.dphase * i
+        s = 1 + runner.amp * np.sin(runner.q * pts[:, 0] + ph) * np.cos(runner.q * pts[:, 1] - 0.5 * ph) * np.sin(runner.q * pts[:, 2] + 0.25 * ph)
+        st = ol.Stats(topo, pts * s[:, None], ol.MIXED if f32 else ol.F64)
+        n, c = st.step(n, c, runner.dt, 1, runner.model.as_array())
+    ol.set_threads(1)
+    g = state
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    return {"rel_l2_n": rel(g[0], n), "rel_l2_c": rel(g[1], c), "steps": total_steps, "tolerance": 2e-5 if f32 else 1e-11,
+            "oracle": "fo_assemble_%s of the re-deformed mesh + fo_step per iteration (oracle/, %d threads), %.1f s"
+                      % ("mixed" if f32 else "f64", threads, time.perf_counter() - t0)}
 
 
 def verify_against_oracle(runner, state, total_steps, seed=1):
@@ -113,6 +178,7 @@ def main():
     ap.add_argument("--fuse", type=int, default=None,
                     help="time steps fused per launch (0 = single-step sliced-ELL kernel); default FEM_FUSE_STEPS, "
                          "else the measured best: 7 on the spheres, 5 on the irregular scanned-like meshes")
+    ap.add_argument("--unfused", action="store_true", help="deform workloads: assembly kernel, then step kernel (two kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed run's result (N=1, warmup+steps <= 64)")
     ap.add_argument("--sustained-steps", type=int, default=1000,
@@ -179,7 +245,14 @@ def main():
     tile_n0 = int(os.environ.get("FEM_TILE_N0", ({4: "950", 5: "820" if scanned else "880", 6: "760", 7: "650"} if small else
                                                  {5: "1200", 6: "1050", 7: "975", 8: "900"}).get(args.fuse, "820")))
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
-    if world > 1:
+    deform = wl.get("deform", False)
+    if deform:
+        if world > 1:
+            raise SystemExit("bench.py: the deforming-mesh workloads run on one GPU")
+        from fem_amd import dist as fdist
+        args.fuse, nparts = 0, max(1, V_total // wl["verts_per_part"])
+        runner = fdist.DeformRun(mesh, nparts, args.precision, fused=not args.unfused)
+    elif world > 1:
         from fem_amd import dist as fdist
         runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse, dt_rule=dt_rule,
                                   control_group=control)
@@ -216,9 +289,9 @@ def main():
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
-    final_state, sustained = None, None
+    final_state, sustained, asm_ms = None, None, None
     if world == 1:
-        if not args.no_verify and args.warmup + args.steps <= 64:
+        if not args.no_verify and args.warmup + args.steps <= (32 if deform else 64):
             final_state = runner.plan.get_state()              # what the timed kernel left; checked below, outside all timing
         if args.sustained_steps > 0 and args.sustained_steps != args.steps:
             torch.cuda.synchronize()
@@ -232,6 +305,15 @@ def main():
             sustained = {"steps": args.sustained_steps, "value": 2.0 * V_total * args.sustained_steps / tw,
                          "ms_per_step": tw * 1e3 / args.sustained_steps,
                          "device_ms_per_step": s0.elapsed_time(s1) / args.sustained_steps}
+        if deform:
+            # the dominant kernel alone (no deformation kernel between the launches), device events on its stream
+            reps = max(10, min(200, args.steps))
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(stream)
+            runner.run(reps, stream, deform=False)
+            a1.record(stream)
+            torch.cuda.synchronize()
+            asm_ms = a0.elapsed_time(a1) / reps
     if world > 1:
         staged = getattr(runner, "host_group", None)
         tmax = torch.tensor([wall, dev_ms], dtype=torch.float64,
@@ -246,6 +328,9 @@ def main():
         kernel_ms = dev_ms / launches                       # average launch duration, device events
         v_per_launch = runner.vertices_per_launch           # owned vertices this rank advances per launch
         achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch * (args.steps / launches) / (kernel_ms * 1e-3) / 1e9
+        if deform:        # the assembly is the dominant kernel: 68 B per element by SURVEY.md 8(d)
+            kernel_ms = asm_ms
+            achieved = ALG_BYTES_PER_ELEMENT_ASSEMBLY * n_faces / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = runner.measured_traffic()
         out = {
             "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",
@@ -257,7 +342,11 @@ def main():
                                    % (args.workload if args.mesh is None else os.path.basename(args.mesh) + " x4^%d" % args.subdivide,
                                       "surface read from file" if args.mesh is not None else
                                       "scanned-like irregular surface (flipped/fanned/noisy geodesic sphere)"
-                                      if scanned else "class-I geodesic icosphere", wl["nu"], V_total, n_faces, nparts),
+                                      if scanned else ("class-I geodesic icosphere, DEFORMED and re-assembled on the device every step "
+                                                       "(%s)" % ("assembly kernel + step kernel" if args.unfused else "one fused assembly-and-step kernel")
+                                                       if deform else "class-I geodesic icosphere"), wl["nu"], V_total, n_faces, nparts),
+                       "elements_per_s": n_faces * args.steps / wall if deform else None,
+                       "assembly_elements_per_s": n_faces / (asm_ms * 1e-3) if deform else None,
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report, "sustained": sustained,
@@ -270,14 +359,15 @@ def main():
                                             % (runner.traffic_key(), traffic_source)) if traffic else None,
                          "traffic_rate": traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None,
                          "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                         "alg_bytes_per_vertex_step": ALG_BYTES_PER_VERTEX_STEP, "avg_launch_ms": kernel_ms,
+                         "alg_bytes_per_vertex_step": None if deform else ALG_BYTES_PER_VERTEX_STEP,
+                         "alg_bytes_per_element": ALG_BYTES_PER_ELEMENT_ASSEMBLY if deform else None, "avg_launch_ms": kernel_ms,
                          "time_steps_per_launch": args.steps / launches,
                          "layout_bytes_per_launch": runner.layout_bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline_deform() if deform else cpu_baseline()
         if final_state is not None:
-            out["verify"] = verify_against_oracle(runner, final_state, args.warmup + args.steps)
+            out["verify"] = (verify_deform if deform else verify_against_oracle)(runner, final_state, args.warmup + args.steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

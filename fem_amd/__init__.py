@@ -435,6 +435,11 @@ class Plan:
     def assemble(self, stream=None):
         _check(lib.fem_plan_assemble(self.h, vp(stream or 0)))
 
+    def assemble_step(self, dt, model=None, store_operator=False, stream=None):
+        """assembly from the current positions fused with one time step (fem_plan_assemble_step)"""
+        mp = C.byref(model) if model is not None else None
+        _check(lib.fem_plan_assemble_step(self.h, C.c_double(dt), mp, C.c_int(1 if store_operator else 0), vp(stream or 0)))
+
     def max_edge(self):
         v = C.c_double()
         _check(lib.fem_plan_max_edge(self.h, C.byref(v)))

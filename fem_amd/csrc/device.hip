@@ -114,6 +114,7 @@ struct fem_plan {
   bool can_assemble = false;
   bool fan_rows = false;            // every row is one fan in order: assemble_row_fan applies
   bool wide_rows = false;           // some row has more than 6 entries
+  fem_uint max_row = 0;             // entries of the longest row
   fem_uint F = 0, Vg = 0;
   DevBuf<fem_uint> tri0, tri1, tri2, topo, rowg;
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
@@ -165,6 +166,20 @@ template <typename T> static void launchAssemble(fem_plan *p, hipStream_t st) {
     }
   }
   hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, parts * nb, p->maxedge);
+}
+
+// Assembly from the current positions fused with one time step (config 5's iteration minus the deformation).
+template <typename T> static void launchAssembleStep(fem_plan *p, double dt, const fem_model *model, bool store, hipStream_t st) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  const ModelT<T> m = {(T)(model->nMax - p->base_n), (T)model->D, (T)model->r, (T)model->alpha, (T)model->S, (T)dt, (T)p->base_n,
+                       (T)(1.0 / (1.0 + p->base_n))};
+  auto kern = p->max_row <= 6 ? (store ? assemble_step_sell_kernel<T, true, 6> : assemble_step_sell_kernel<T, false, 6>)
+                              : (store ? assemble_step_sell_kernel<T, true, 12> : assemble_step_sell_kernel<T, false, 12>);
+  hipLaunchKernelGGL(kern, dim3(p->nblocks), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p, p->slice_off.p, p->idx.p,
+                     p->rowg.p, (T4 *)p->coef, (const T2 *)p->state[p->cur], (T2 *)p->state[p->cur ^ 1], p->nslices, p->V, m, p->blockmax);
+  hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, p->nblocks, p->maxedge);
+  p->cur ^= 1;
 }
 
 // per-face records (fem_plan_face_records): not needed by the operator, computed on request
@@ -572,7 +587,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     const fem::SimpleTriMesh &m = ordered->mesh;
     p->F = m.n_faces(); p->Vg = m.n_vertices(); p->can_assemble = true;
     p->fan_rows = op.fanOrdered && getenv("FEM_ASSEMBLE_GENERIC") == nullptr;
-    for (fem::uint r = 0; r < op.V && !p->wide_rows; r++) p->wide_rows = op.rowptr[r + 1] - op.rowptr[r] > 6;
+    for (fem::uint r = 0; r < op.V; r++) p->max_row = std::max<fem_uint>(p->max_row, op.rowptr[r + 1] - op.rowptr[r]);
+    p->wide_rows = p->max_row > 6;
     std::vector<fem_uint> t0(p->F), t1(p->F), t2(p->F);
     for (fem_uint f = 0; f < p->F; f++) { t0[f] = m.faces[3 * (size_t)f]; t1[f] = m.faces[3 * (size_t)f + 1]; t2[f] = m.faces[3 * (size_t)f + 2]; }
     const std::vector<fem_uint> &topo = ksteps > 0 ? TL.topo : L.topo;
@@ -814,6 +830,22 @@ int fem_plan_assemble(fem_plan *p, void *stream) {
   else launchAssemble<double>(p, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return FEM_OK;
+}
+
+int fem_plan_assemble_step(fem_plan *p, double dt, const fem_model *model, int store_operator, void *stream) {
+  if (!p || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_assemble_step: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  // the fused kernel: sliced-ELL plans whose rows are fans of at most 12 entries; anything else takes the two
+  // kernels one after the other (same result: the fused kernel applies the coefficients it would have stored)
+  if (p->ksteps == 0 && p->fan_rows && p->max_row <= 12) {
+    if (p->precision == FEM_PREC_F32) launchAssembleStep<float>(p, dt, model, store_operator != 0, (hipStream_t)stream);
+    else launchAssembleStep<double>(p, dt, model, store_operator != 0, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return FEM_OK;
+  }
+  const int rc = fem_plan_assemble(p, stream);
+  return rc != FEM_OK ? rc : fem_plan_run(p, 1, dt, model, stream);
 }
 
 int fem_plan_deform(fem_plan *p, double amplitude, double wavenumber, double phase, void *stream) {

@@ -304,6 +304,85 @@ __device__ __forceinline__ T assemble_row_fan(const typename Vec<T>::t4 *__restr
   return dev_sqrt(maxe2);
 }
 
+// assemble_row_fan + one time step of the row, fused (BASELINE config 5: re-assembly every step): the row's
+// coefficients (w, Cx, Cy, Cz) are applied to the neighbours' state straight from the registers they were
+// assembled in -- lap f = sum w (f_j - f_v), G f = sum C (f_j - f_v), then reaction_update, the arithmetic
+// of sell_step_kernel entry by entry in the same order -- so the 96-B row of the operator does not make the
+// round trip through HBM between an assembly kernel and a step kernel (STORE = true writes it as well, for a
+// caller that keeps stepping on it).  idx[] = the row ids of the neighbours (the sliced-ELL column array).
+template <typename T, int W, bool STORE>
+__device__ __forceinline__ T assemble_row_fan_step(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
+                                                   const uint *__restrict__ idx, typename Vec<T>::t4 *__restrict__ coef,
+                                                   const typename Vec<T>::t2 *__restrict__ src, uint vg, uint row, size_t first,
+                                                   uint width, const ModelT<T> &m, typename Vec<T>::t2 &out) {
+  typedef typename Vec<T>::t4 T4;
+  typedef typename Vec<T>::t2 T2;
+  auto at = [&](int k) { return first + (size_t)k * 64; };
+  const T4 P = pos[vg];
+  const T2 self = src[row];
+  T area3 = 0, theta = 0, maxe2 = 0;
+  uint2 t[W];                                        // loads unconditional, as in assemble_row
+  uint col[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const size_t e = at((uint)k < width ? k : 0);
+    const uint2 q = topo[e];
+    t[k].x = q.x;
+    t[k].y = (uint)k < width ? q.y : 0xffffu;
+    col[k] = idx[e];
+  }
+  T e[W][3];
+  T4 acc[W];
+  T2 f[W];
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const T4 J = pos[t[k].x];
+    f[k] = src[col[k]];
+    e[k][0] = J.x - P.x; e[k][1] = J.y - P.y; e[k][2] = J.z - P.z;
+    acc[k].x = acc[k].y = acc[k].z = acc[k].w = 0;
+  }
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    const uint s1 = t[k].y & 0xffu;
+    const bool real = (t[k].y >> 16) & 1u, has1 = real && s1 < (uint)W;
+    const bool wrap = (k + 1 == W) || s1 == 0u;
+    const int kn = k + 1 < W ? k + 1 : 0;
+    T en[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) en[d] = wrap ? e[0][d] : e[kn][d];
+    if (has1) {
+      const FanFace<T> ff = fan_face<T>(e[k], en);
+      const T rcn = dev_rsqrt(ff.c2);
+      const T ang = dev_acos(ff.d * dev_rsqrt(ff.l1 * ff.l2));
+      const T s = ang * rcn * rcn;
+      acc[k].x += (ff.l2 - ff.d) * rcn;
+      acc[k].y += s * (en[1] * ff.cz - en[2] * ff.cy); acc[k].z += s * (en[2] * ff.cx - en[0] * ff.cz); acc[k].w += s * (en[0] * ff.cy - en[1] * ff.cx);
+      T4 nx;
+      nx.x = (ff.l1 - ff.d) * rcn;
+      nx.y = s * (ff.cy * e[k][2] - ff.cz * e[k][1]); nx.z = s * (ff.cz * e[k][0] - ff.cx * e[k][2]); nx.w = s * (ff.cx * e[k][1] - ff.cy * e[k][0]);
+      if (wrap) { acc[0].x += nx.x; acc[0].y += nx.y; acc[0].z += nx.z; acc[0].w += nx.w; }
+      else { acc[kn].x += nx.x; acc[kn].y += nx.y; acc[kn].z += nx.z; acc[kn].w += nx.w; }
+      theta += ang; area3 += ff.c2 * rcn * (T)(1.0 / 6.0);
+    }
+    if (real) maxe2 = fmax(maxe2, e[k][0] * e[k][0] + e[k][1] * e[k][1] + e[k][2] * e[k][2]);
+  }
+  const RowScale<T> rs = row_scale<T>(area3, theta);
+  T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+#pragma unroll
+  for (int k = 0; k < W; k++) {
+    if ((uint)k < width) {
+      const T4 c = entry_scale<T>(acc[k], rs);
+      if (STORE) coef[at(k)] = c;
+      const T dn = f[k].x - self.x, dc = f[k].y - self.y;
+      lapn += c.x * dn; lapc += c.x * dc;
+      gnx += c.y * dn; gny += c.z * dn; gnz += c.w * dn;
+      gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
+    }
+  }
+  out = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+  return dev_sqrt(maxe2);
+}
+
 template <typename T>
 __device__ __forceinline__ T assemble_row_wide(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
                                                typename Vec<T>::t4 *__restrict__ coef, uint vg, size_t first, size_t stride,
@@ -376,6 +455,37 @@ __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename 
       else e = assemble_row_wide<T>(pos, topo, coef, vg, first, rpad, W + nx, xfirst);
     }
     me = fmax(me, e);
+  }
+  block_max_256((double)me, blockMax);
+}
+
+// Fused assembly + step over a sliced-ELL plan whose rows are all fans of at most 12 entries (regular and mildly
+// irregular meshes); one wave64 per slice like sell_step_kernel / assemble_rows_sell_kernel.
+// MAXW = 6: plans without a row of more than 6 entries (small register footprint, as PART = 1 above); 12: any
+template <typename T, bool STORE, int MAXW>
+__global__ __launch_bounds__(256) void assemble_step_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
+                                                                 const uint2 *__restrict__ topo, const uint *__restrict__ slice_off,
+                                                                 const uint *__restrict__ idx, const uint *__restrict__ rowg,
+                                                                 typename Vec<T>::t4 *__restrict__ coef,
+                                                                 const typename Vec<T>::t2 *__restrict__ src,
+                                                                 typename Vec<T>::t2 *__restrict__ dst, uint nslices, uint V,
+                                                                 ModelT<T> m, double *__restrict__ blockMax) {
+  typedef typename Vec<T>::t2 T2;
+  const uint slice = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+  T me = 0;
+  if (slice < nslices) {
+    const uint off = slice_off[slice], width = (slice_off[slice + 1] - off) >> 6;
+    const uint v = slice * 64 + lane, row = min(v, V - 1);
+    const uint vg = rowg[row];
+    T2 o = src[row];
+    if (width == 0) {
+      o = reaction_update<T>(o, 0, 0, 0, 0, 0, 0, 0, 0, m);            // a slice of isolated vertices: reaction only
+    } else if (MAXW <= 6 || width <= 6) {
+      me = assemble_row_fan_step<T, 6, STORE>(pos, topo, idx, coef, src, vg, row, (size_t)off + lane, width, m, o);
+    } else if constexpr (MAXW > 6) {
+      me = assemble_row_fan_step<T, 12, STORE>(pos, topo, idx, coef, src, vg, row, (size_t)off + lane, width, m, o);
+    }
+    if (v < V) dst[v] = o;
   }
   block_max_256((double)me, blockMax);
 }

@@ -64,6 +64,54 @@ class SingleRun:
         return hit.get("hbm_bytes_per_launch"), hit.get("source")
 
 
+class DeformRun:
+    """BASELINE config 5: a deforming mesh, the operator re-assembled on the device every time step.
+    One iteration = deform kernel (seeded smooth radial displacement, phase advancing per step) + the fused
+    assembly + step kernel (fem_plan_assemble_step); `fused=False`: assembly kernel, then step kernel."""
+    def __init__(self, mesh, nparts, precision="f32", seed=1, fused=True):
+        self.kernel_name = "assemble_step_sell_kernel" if fused else "assemble_rows_sell_kernel"
+        self.fused = fused
+        self.part = mesh.partition(nparts)
+        om = self.part.ordered
+        om.init_stats(fa.PREC_F64)
+        self.model = fa.default_model()
+        self.dt = 0.08 * om.stats()["maxEdgeLen"] ** 2          # inside the explicit limit for every deformed state
+        self.precision = precision
+        self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, part=self.part, ksteps=0, assemble=True)
+        self.seed = seed
+        n0, c0 = fa.initial_condition(om.V, seed)
+        self.plan.set_state(n0, c0)
+        self.V, self.F = om.V, om.F
+        self.vertices_per_launch = om.V
+        self.steps_per_launch = 1
+        self.amp, self.q, self.dphase = 0.01, 2 * np.pi / 4.0, 0.01
+        self.iteration = 0
+        self.layout_bytes_per_launch = None
+
+    def run(self, nsteps, stream=None, deform=True):
+        s = stream.cuda_stream if stream is not None else None
+        for _ in range(nsteps):
+            if deform:
+                self.plan.deform(self.amp, self.q, self.dphase * self.iteration, s)
+            if self.fused:
+                self.plan.assemble_step(self.dt, self.model, False, s)
+            else:
+                self.plan.assemble(s)
+                self.plan.run(1, self.dt, self.model, s)
+            self.iteration += 1
+
+    def traffic_key(self):
+        return "%s:%s:%d" % (self.kernel_name, self.precision, self.V)
+
+    def measured_traffic(self):
+        path = os.path.join(_PROFILES, "traffic.json")
+        if not os.path.exists(path):
+            return None, None
+        with open(path) as f:
+            hit = json.load(f).get(self.traffic_key())
+        return (hit.get("hbm_bytes_per_launch"), hit.get("source")) if isinstance(hit, dict) else (None, None)
+
+
 class _DevView:
     """zero-copy view of device memory owned by the library, for torch.as_tensor"""
 

@@ -270,6 +270,15 @@ int fem_plan_deform(fem_plan *p, double amplitude, double wavenumber, double pha
  * plan's operator array.  Arithmetic type = the plan's precision (FEM_PREC_F32 ~ the reference's
  * Vec3f geometry). */
 int fem_plan_assemble(fem_plan *p, void *stream);
+/* One iteration of a deforming-mesh run (BASELINE config 5: re-assembly every step) in one kernel: the assembly of
+ * fem_plan_assemble from the current positions, and one explicit time step (fem_plan_run(p, 1, ...)) taken with the
+ * coefficients while they are still in the registers they were assembled in, so that the operator does not travel
+ * through HBM between two kernels.  store_operator != 0 also writes the operator into the plan (for later
+ * fem_plan_run calls on it); with 0 the plan's stored operator is left as it was.  maxEdgeLen is updated either way
+ * (fem_plan_max_edge): dt is the caller's, e.g. from the previous iteration's edge length.  Fused for sliced-ELL
+ * plans (ksteps = 0) whose rows are single fans of at most 12 entries; other plans run the two kernels in turn,
+ * with the same result. */
+int fem_plan_assemble_step(fem_plan *p, double dt, const fem_model *model, int store_operator, void *stream);
 /* maxEdgeLen of the last fem_plan_assemble (dt = 0.1 maxEdgeLen^2, main.cpp:188); synchronises */
 int fem_plan_max_edge(fem_plan *p, double *maxEdgeLen);
 /* per-face records of the last assembly, 16 doubles per face:

@@ -123,3 +123,110 @@ def test_non_manifold_vertex_falls_back_to_slot_table():
         plan.assemble()
         dev = plan.coef()
         assert np.abs(dev - host).max() <= 1e-11 * np.abs(host).max()
+
+
+def _config5_loop(case, prec, mode, iters=6):
+    """deform(phase_i) -> assemble -> one step, `iters` times; returns the final state and the per-iteration
+    maxEdgeLen the device reported.  mode: "sell" / "tile" = assembly kernel then step kernel on that layout,
+    "fused" / "fused+store" = fem_plan_assemble_step"""
+    case.mesh.init_stats(fa.PREC_F64 if prec == "f64" else fa.PREC_MIXED)
+    plan = fa.Plan(case.mesh, fa.PREC_F64 if prec == "f64" else fa.PREC_F32, part=case.part,
+                   ksteps=2 if mode == "tile" else 0, assemble=True)
+    plan.set_state(case.n0, case.c0)
+    edges = []
+    for i in range(iters):
+        plan.deform(0.03, 0.9, 0.35 * i)
+        if mode.startswith("fused"):
+            plan.assemble_step(case.dt_loop, case.model, store_operator=mode.endswith("store"))
+        else:
+            plan.assemble()
+            plan.run(1, case.dt_loop, case.model)
+        edges.append(plan.max_edge())
+    return plan.get_state(), edges, plan
+
+
+def _config5_oracle(case, prec, iters=6):
+    n, c = case.n0.copy(), case.c0.copy()
+    if prec == "f32":
+        n, c = n.astype(np.float32).astype(np.float64), c.astype(np.float32).astype(np.float64)
+    edges = []
+    for i in range(iters):
+        st = ol.Stats(case.topo, deformed(case.pts, 0.03, 0.9, 0.35 * i), ol.F64 if prec == "f64" else ol.MIXED)
+        n, c = st.step(n, c, case.dt_loop, 1, case.model.as_array())
+        edges.append(st.maxEdgeLen)
+    return (n, c), edges
+
+
+@pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(20, n), 8),
+                                         (lambda n: Case(*fa.make_scanned_like(20, 0.1, seed=5, flip_fraction=0.15, high_valence_fraction=0.0), n), 6),
+                                         (lambda n: scan_case(16, n), 5)])
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_config5_iteration_loop_vs_oracle(make, nparts, prec):
+    """BASELINE config 5 as a loop: six iterations of deform -> re-assemble -> step with a different deformation
+    each time, against the oracle re-assembling the deformed positions on the CPU every iteration.  All four
+    device paths: assembly + step kernels on the sliced-ELL and the tile layout, and the fused kernel with and
+    without storing the operator (regular mesh: 6-entry rows; flipped mesh: up to 12; fanned mesh: wider rows,
+    where fem_plan_assemble_step falls back to the two kernels)."""
+    case = make(nparts)
+    st0 = case.ostats(ol.F64)
+    case.dt_loop = min(0.08 * st0.maxEdgeLen ** 2, 0.8 * 0.2 / (max(1.0, case.model.D) * np.abs(st0.wVtx).max()))
+    (n_ref, c_ref), e_ref = _config5_oracle(case, prec)
+    tol = 1e-11 if prec == "f64" else 2e-5
+    outs = {}
+    for mode in ("sell", "tile", "fused", "fused+store"):
+        (n, c), edges, plan = _config5_loop(case, prec, mode)
+        assert rel_l2(n, n_ref) <= tol and rel_l2(c, c_ref) <= tol, (mode, rel_l2(n, n_ref), rel_l2(c, c_ref))
+        assert np.abs(np.array(edges) - np.array(e_ref)).max() <= (1e-12 if prec == "f64" else 2e-5) * max(e_ref), mode
+        outs[mode] = (n, c)
+        if mode == "fused+store":          # the stored operator is the one of the last deformation: one more plain step on it
+            plan.run(1, case.dt_loop, case.model)
+            st = ol.Stats(case.topo, deformed(case.pts, 0.03, 0.9, 0.35 * 5), ol.F64 if prec == "f64" else ol.MIXED)
+            n2, c2 = st.step(n_ref, c_ref, case.dt_loop, 1, case.model.as_array())
+            g = plan.get_state()
+            assert rel_l2(g[0], n2) <= tol and rel_l2(g[1], c2) <= tol
+    # fused and unfused apply the same coefficients in the same order (two kernels: the compiler may contract a
+    # multiply-add differently, hence a few ulp, not bit for bit)
+    for other in ("sell", "fused+store"):
+        assert rel_l2(outs["fused"][0], outs[other][0]) <= (1e-13 if prec == "f64" else 1e-6)
+
+
+def test_config5_full_size_properties():
+    """nu = 640 (V = 4 096 002, the size BASELINE config 5 names), fp32, fused assembly + step: a constant state is a
+    fixed point of the freshly assembled operator on every deformed mesh (rows sum to zero by construction); two runs
+    of the same five iterations agree bit for bit (no atomics anywhere in the assembly); the fused kernel and the
+    two-kernel path agree; the edge length follows the deformation"""
+    pts, tri = fa.make_icosphere(640, 0.1)
+    mesh = fa.Mesh(pts, tri)
+    part = mesh.partition(mesh.V // 256)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = 0.08 * om.stats()["maxEdgeLen"] ** 2
+    model = fa.default_model()
+    plan = fa.Plan(om, fa.PREC_F32, part=part, ksteps=0, assemble=True)
+    q = 2 * np.pi / 4.0
+    m0 = fa.default_model()
+    m0.r = 0.0
+    n_const = np.full(om.V, 0.75)
+    plan.set_state(n_const, n_const / (1 + n_const))
+    for i in range(3):
+        plan.deform(0.01, q, 0.3 * i)
+        plan.assemble_step(dt, m0)
+    n1, c1 = plan.get_state()
+    assert np.array_equal(n1, n_const.astype(np.float32).astype(np.float64)) and np.abs(c1 - n_const / (1 + n_const)).max() <= 1e-6
+    n0, c0 = fa.initial_condition(om.V, 2)
+    runs = []
+    for fused in (True, True, False):
+        plan.set_state(n0, c0)
+        edges = []
+        for i in range(5):
+            plan.deform(0.01, q, 0.3 * i)
+            if fused:
+                plan.assemble_step(dt, model)
+            else:
+                plan.assemble()
+                plan.run(1, dt, model)
+            edges.append(plan.max_edge())
+        runs.append((plan.get_state(), edges))
+    assert np.array_equal(runs[0][0][0], runs[1][0][0]) and np.array_equal(runs[0][0][1], runs[1][0][1])
+    assert rel_l2(runs[0][0][0], runs[2][0][0]) <= 1e-6 and runs[0][1] == runs[2][1]
+    assert len(set(runs[0][1])) == 5 and np.isfinite(runs[0][0][0]).all() and runs[0][0][0].min() >= 0

@@ -389,3 +389,27 @@ def test_ply_reader(tmp_path):
     for name in "cdef":
         with pytest.raises(fa.FemError):
             fa.ply_read(str(tmp_path / (name + ".ply")))
+
+
+def test_shard_restricted_assembly_rows_are_bit_identical():
+    """fem_mesh_init_stats_shard: the rows of a shard's local vertices equal the full assembly's bit for bit, nothing
+    else is assembled, maxEdgeLen stays the whole mesh's (dt must agree on every rank)"""
+    pts, tri = fa.make_scanned_like(24, 0.1, seed=3, high_valence_fraction=0.01)
+    part = fa.Mesh(pts, tri).partition(30)
+    om = part.ordered
+    for prec in (fa.PREC_F64, fa.PREC_MIXED):
+        om.init_stats(prec)
+        full = om.stats()
+        shard = fa.Shard(part, 1, 3, 4)
+        om.init_stats_shard(prec, shard)
+        loc = om.stats()
+        l2g = shard.loc2glob.astype(np.int64)
+        assert len(l2g) < om.V
+        for key in ("wVtx", "areaPerVtx"):
+            assert np.array_equal(full[key][l2g], loc[key][l2g])
+            rest = np.ones(om.V, bool)
+            rest[l2g] = False
+            assert (loc["wVtx"][rest] == 0).all()
+        rows = np.isin(om.topology()["he_from"], l2g)
+        assert np.array_equal(full["wHej"][rows], loc["wHej"][rows]) and (loc["wHej"][~rows] == 0).all()
+        assert loc["maxEdgeLen"] == full["maxEdgeLen"]
