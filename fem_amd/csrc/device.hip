@@ -115,6 +115,7 @@ struct fem_plan {
   bool fan_rows = false;            // every row is one fan in order: assemble_row_fan applies
   bool wide_rows = false;           // some row has more than 6 entries
   fem_uint max_row = 0;             // entries of the longest row
+  bool rows_are_vertices = false;   // row r is mesh vertex r (whole-mesh plan): a neighbour's mesh id is its row id
   fem_uint F = 0, Vg = 0;
   DevBuf<fem_uint> tri0, tri1, tri2, topo, rowg;
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
@@ -174,8 +175,12 @@ template <typename T> static void launchAssembleStep(fem_plan *p, double dt, con
   typedef typename Vec<T>::t4 T4;
   const ModelT<T> m = {(T)(model->nMax - p->base_n), (T)model->D, (T)model->r, (T)model->alpha, (T)model->S, (T)dt, (T)p->base_n,
                        (T)(1.0 / (1.0 + p->base_n))};
-  auto kern = p->max_row <= 6 ? (store ? assemble_step_sell_kernel<T, true, 6> : assemble_step_sell_kernel<T, false, 6>)
-                              : (store ? assemble_step_sell_kernel<T, true, 12> : assemble_step_sell_kernel<T, false, 12>);
+  auto pick = [&](auto ident) {
+    constexpr bool ID = decltype(ident)::value;
+    return p->max_row <= 6 ? (store ? assemble_step_sell_kernel<T, true, 6, ID> : assemble_step_sell_kernel<T, false, 6, ID>)
+                           : (store ? assemble_step_sell_kernel<T, true, 12, ID> : assemble_step_sell_kernel<T, false, 12, ID>);
+  };
+  auto kern = p->rows_are_vertices ? pick(std::true_type()) : pick(std::false_type());
   hipLaunchKernelGGL(kern, dim3(p->nblocks), dim3(256), 0, st, (const T4 *)p->pos, (const uint2 *)p->topo.p, p->slice_off.p, p->idx.p,
                      p->rowg.p, (T4 *)p->coef, (const T2 *)p->state[p->cur], (T2 *)p->state[p->cur ^ 1], p->nslices, p->V, m, p->blockmax);
   hipLaunchKernelGGL(max_reduce_kernel, dim3(1), dim3(1024), 0, st, (const double *)p->blockmax, p->nblocks, p->maxedge);
@@ -589,6 +594,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     p->fan_rows = op.fanOrdered && getenv("FEM_ASSEMBLE_GENERIC") == nullptr;
     for (fem::uint r = 0; r < op.V; r++) p->max_row = std::max<fem_uint>(p->max_row, op.rowptr[r + 1] - op.rowptr[r]);
     p->wide_rows = p->max_row > 6;
+    p->rows_are_vertices = op.V == p->Vg;
+    for (fem::uint r = 0; r < op.V && p->rows_are_vertices; r++) p->rows_are_vertices = op.rowg[r] == r;
     std::vector<fem_uint> t0(p->F), t1(p->F), t2(p->F);
     for (fem_uint f = 0; f < p->F; f++) { t0[f] = m.faces[3 * (size_t)f]; t1[f] = m.faces[3 * (size_t)f + 1]; t2[f] = m.faces[3 * (size_t)f + 2]; }
     const std::vector<fem_uint> &topo = ksteps > 0 ? TL.topo : L.topo;

@@ -1,10 +1,6 @@
-// fem_host.hpp -- host side of the FEM hot path (C++17, no OpenMesh/METIS).
-//
-// Keeps the reference's host interface names for this path on the build's own
-// mesh type: SimpleTriMesh (reference src/common.h:41-52), MeshStats
-// (common.h:19-38), initMeshStats/deleteMeshStats (mesh_function.h:124-125),
-// computeLaplacianCPU/computeFaceGradientsCPU/computeVertexGradientsCPU
-// (mesh_function.h:6-110), partition (partitioning_common.h:3-9).
+// fem_host.hpp (private) -- the host side's internals: device layouts, packers, shards, worker threads.
+// The reference-named public interfaces (SimpleTriMesh, MeshStats, initMeshStats, compute*CPU, partition, mesh IO)
+// are declared in include/fem_host.hpp.
 #pragma once
 
 #include <cstdint>
@@ -13,98 +9,9 @@
 #include <utility>
 #include <vector>
 
-#include "../../include/fem_hip.h"
+#include "../../include/fem_host.hpp"
 
 namespace fem {
-
-typedef unsigned int uint;
-
-// Indexed triangle mesh + the half-edge tables the path needs.
-// Conventions (DESIGN.md "Topology conventions"):
-//   interior half-edge h = 3f+k runs faces[3f+k] -> faces[3f+(k+1)%3];
-//   boundary half-edges are 3F+b, in ascending order of their interior
-//   opposite; halfedge_handle(f) is the last one (c->a), so fv/fh iteration
-//   yields a, b, c and (v1, v2, v3) = (c, a, b);
-//   voh(v) = outgoing half-edges in ascending to-vertex order.
-struct SimpleTriMesh {
-  std::vector<double> points;          // 3V
-  std::vector<uint> faces;             // 3F
-  std::vector<unsigned char> colors;   // 3V or empty
-
-  int H = 0;                           // half-edges incl. boundary; 0 = topology not built
-  std::vector<int32_t> opp;            // [H]
-  std::vector<uint> he_from, he_to;    // [H]
-  std::vector<int32_t> rowptr;         // [V+1]
-  std::vector<uint> col;               // [H]  to-vertex, ascending per row
-  std::vector<int32_t> row_he;         // [H]  half-edge id of that entry
-
-  uint n_vertices() const { return (uint)(points.size() / 3); }
-  uint n_faces() const { return (uint)(faces.size() / 3); }
-  uint n_halfedges() const { return (uint)H; }
-  uint add_vertex(const double *p) {
-    points.insert(points.end(), p, p + 3);
-    H = 0;
-    return n_vertices() - 1;
-  }
-  uint add_face(uint a, uint b, uint c) {
-    faces.push_back(a); faces.push_back(b); faces.push_back(c);
-    H = 0;
-    return n_faces() - 1;
-  }
-  void clean() { points.clear(); faces.clear(); colors.clear(); H = 0; }
-  bool is_boundary(int h) const { return h >= 3 * (int)n_faces(); }
-  static int next_halfedge(int h) { return (h / 3) * 3 + (h % 3 + 1) % 3; }
-  static int prev_halfedge(int h) { return (h / 3) * 3 + (h % 3 + 2) % 3; }
-  int update_topology();               // FEM_OK / FEM_ERR_INVALID / FEM_ERR_NONMANIFOLD
-};
-
-// Hot fields of the reference's MeshStats (common.h:19-38).  gradVec12/13 are
-// stored as doubles; in FEM_PREC_MIXED they hold float-rounded values.
-struct MeshStats {
-  int precision = -1;
-  std::vector<double> meshAngle, meshCot;    // [H]
-  std::vector<double> meshArea;              // [F]
-  std::vector<double> wHej;                  // [H]
-  std::vector<double> wVtx, areaPerVtx;      // [V]
-  std::vector<double> gradVec12, gradVec13;  // [3F]
-  double maxEdgeLen = 0;
-};
-
-void initMeshStats(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision = FEM_PREC_MIXED);
-// the same for the operator rows of the listed vertices only (a shard's local rows): entries no listed row needs stay 0
-void initMeshStatsRows(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision, const std::vector<uint> &rows);
-void deleteMeshStats(MeshStats &mStats);
-
-bool computeLaplacianCPU(const SimpleTriMesh &m, const double *fn, double *lap,
-                         const double *wHej, const double *wVtx);
-bool computeFaceGradientsCPU(const SimpleTriMesh &m, const double *gradV12, const double *gradV13,
-                             double *opGrad, const double *fn, int precision);
-bool computeVertexGradientsCPU(const SimpleTriMesh &m, const double *faceGrad, double *opVtxGrad,
-                               const double *meshAngles, int precision);
-
-// partitioning_common.h:3-9 on the build's mesh type (same argument order).
-int partition(const SimpleTriMesh &originalMesh, SimpleTriMesh *orderedMesh, uint **node_parts,
-              uint **element_parts, int n);
-
-// pieces of the above (partitioning_common.cpp:32-176)
-int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart);          // coordinate bisection
-int partitionVerticesGraph(const SimpleTriMesh &m, int n, int64_t *npart);     // graph bisection (needs topology)
-void faceParts(const SimpleTriMesh &m, const int64_t *npart, int n, int64_t *epart);
-int createOrderArray(uint *parts, int64_t *part, int64_t N, int n);
-void reorderMesh(const SimpleTriMesh &original, SimpleTriMesh *ordered, const int64_t *npart,
-                 const int64_t *epart);
-int64_t edgeCut(const SimpleTriMesh &m, const int64_t *npart);
-
-// mesh IO + synthetic inputs
-int readOFF(const std::string &path, SimpleTriMesh &m);
-int readPLY(const std::string &path, SimpleTriMesh &m);
-int writeOFF(const std::string &path, const SimpleTriMesh &m);
-int makeIcosphere(int nu, double edge, SimpleTriMesh &m);
-int makeStrip(int nx, int ny, double h, SimpleTriMesh &m);
-int makeScannedLike(int nu, double edge, uint seed, double flipFraction, double noiseAmp, double highValFraction,
-                    int highVal, SimpleTriMesh &m);
-int subdivide(const SimpleTriMesh &in, int levels, SimpleTriMesh &out);
-void initialCondition(int V, uint seed, double nMax, double *nFn, double *cFn);
 
 // Reference device layout (initializeGPUData, main.cpp:207-342), dense host form.
 struct RefLayout {

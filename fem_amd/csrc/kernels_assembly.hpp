@@ -310,7 +310,9 @@ __device__ __forceinline__ T assemble_row_fan(const typename Vec<T>::t4 *__restr
 // of sell_step_kernel entry by entry in the same order -- so the 96-B row of the operator does not make the
 // round trip through HBM between an assembly kernel and a step kernel (STORE = true writes it as well, for a
 // caller that keeps stepping on it).  idx[] = the row ids of the neighbours (the sliced-ELL column array).
-template <typename T, int W, bool STORE>
+// IDENT: the plan's rows are the mesh's vertices in order (a whole-mesh plan), so the neighbour's mesh id in the table
+// IS its row id and the column array is not read at all (24 B per row less).
+template <typename T, int W, bool STORE, bool IDENT>
 __device__ __forceinline__ T assemble_row_fan_step(const typename Vec<T>::t4 *__restrict__ pos, const uint2 *__restrict__ topo,
                                                    const uint *__restrict__ idx, typename Vec<T>::t4 *__restrict__ coef,
                                                    const typename Vec<T>::t2 *__restrict__ src, uint vg, uint row, size_t first,
@@ -329,7 +331,7 @@ __device__ __forceinline__ T assemble_row_fan_step(const typename Vec<T>::t4 *__
     const uint2 q = topo[e];
     t[k].x = q.x;
     t[k].y = (uint)k < width ? q.y : 0xffffu;
-    col[k] = idx[e];
+    col[k] = IDENT ? q.x : idx[e];
   }
   T e[W][3];
   T4 acc[W];
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(256) void assemble_rows_tile_kernel(const typename 
 // Fused assembly + step over a sliced-ELL plan whose rows are all fans of at most 12 entries (regular and mildly
 // irregular meshes); one wave64 per slice like sell_step_kernel / assemble_rows_sell_kernel.
 // MAXW = 6: plans without a row of more than 6 entries (small register footprint, as PART = 1 above); 12: any
-template <typename T, bool STORE, int MAXW>
+template <typename T, bool STORE, int MAXW, bool IDENT>
 __global__ __launch_bounds__(256) void assemble_step_sell_kernel(const typename Vec<T>::t4 *__restrict__ pos,
                                                                  const uint2 *__restrict__ topo, const uint *__restrict__ slice_off,
                                                                  const uint *__restrict__ idx, const uint *__restrict__ rowg,
@@ -481,9 +483,9 @@ __global__ __launch_bounds__(256) void assemble_step_sell_kernel(const typename 
     if (width == 0) {
       o = reaction_update<T>(o, 0, 0, 0, 0, 0, 0, 0, 0, m);            // a slice of isolated vertices: reaction only
     } else if (MAXW <= 6 || width <= 6) {
-      me = assemble_row_fan_step<T, 6, STORE>(pos, topo, idx, coef, src, vg, row, (size_t)off + lane, width, m, o);
+      me = assemble_row_fan_step<T, 6, STORE, IDENT>(pos, topo, idx, coef, src, vg, row, (size_t)off + lane, width, m, o);
     } else if constexpr (MAXW > 6) {
-      me = assemble_row_fan_step<T, 12, STORE>(pos, topo, idx, coef, src, vg, row, (size_t)off + lane, width, m, o);
+      me = assemble_row_fan_step<T, 12, STORE, IDENT>(pos, topo, idx, coef, src, vg, row, (size_t)off + lane, width, m, o);
     }
     if (v < V) dst[v] = o;
   }

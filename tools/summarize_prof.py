@@ -4,7 +4,8 @@
 usage: tools/summarize_prof.py TAG STATS_DIR [FETCH_DIR WRITE_DIR KEY]
   STATS_DIR : output of `rocprofv3 --kernel-trace --stats --output-format csv`
   FETCH_DIR / WRITE_DIR : outputs of separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
-  KEY : "kernel:precision:V" entry under which bench.py looks the traffic up (profiles/traffic.json)
+  KEY : the runner's traffic_key() (kernel:precision:V:k<steps>:<threads>x<rows>:p<partitions>) under which bench.py
+        looks the traffic up (profiles/traffic.json)
 HBM traffic per launch = 2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports
 half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact.
 """
@@ -56,5 +57,5 @@ if len(sys.argv) > 5:
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
     for k, v in summary.items():
         if kern in k and "hbm_bytes_per_launch" in v:
-            t[key] = v["hbm_bytes_per_launch"]
+            t[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "source": "profiles/%s_pmc.json" % tag}
     json.dump(t, open(tpath, "w"), indent=1)
