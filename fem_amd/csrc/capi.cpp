@@ -43,6 +43,7 @@ const char *fem_error_string(int status) {
 void fem_free(void *p) { free(p); }
 
 int fem_off_read(const char *path, int *V, int *F, double **points, fem_uint **tri, unsigned char **rgb) {
+  return fem::guarded("fem_off_read", [&]() -> int {
   if (!path || !V || !F || !points || !tri) return fail(FEM_ERR_INVALID, "fem_off_read: null");
   fem::SimpleTriMesh m;
   int rc = fem::readOFF(path, m);
@@ -50,9 +51,11 @@ int fem_off_read(const char *path, int *V, int *F, double **points, fem_uint **t
   rc = exportMesh(m, V, F, points, tri);
   if (rc == FEM_OK && rgb) *rgb = m.colors.empty() ? nullptr : dupArray(m.colors);
   return rc;
+  });
 }
 
 int fem_ply_read(const char *path, int *V, int *F, double **points, fem_uint **tri, unsigned char **rgb) {
+  return fem::guarded("fem_ply_read", [&]() -> int {
   if (!path || !V || !F || !points || !tri) return fail(FEM_ERR_INVALID, "fem_ply_read: null");
   fem::SimpleTriMesh m;
   int rc = fem::readPLY(path, m);
@@ -60,10 +63,12 @@ int fem_ply_read(const char *path, int *V, int *F, double **points, fem_uint **t
   rc = exportMesh(m, V, F, points, tri);
   if (rc == FEM_OK && rgb) *rgb = m.colors.empty() ? nullptr : dupArray(m.colors);
   return rc;
+  });
 }
 
 int fem_off_write(const char *path, int V, int F, const double *points, const fem_uint *tri,
                   const unsigned char *rgb) {
+  return fem::guarded("fem_off_write", [&]() -> int {
   if (!path || V < 0 || F < 0 || (V && !points) || (F && !tri)) return fail(FEM_ERR_INVALID, "fem_off_write: bad argument");
   fem::SimpleTriMesh m;
   m.points.assign(points, points + 3 * (size_t)V);
@@ -71,33 +76,41 @@ int fem_off_write(const char *path, int V, int F, const double *points, const fe
   if (rgb) m.colors.assign(rgb, rgb + 3 * (size_t)V);
   int rc = fem::writeOFF(path, m);
   return rc == FEM_OK ? rc : fail(rc, path);
+  });
 }
 
 int fem_make_icosphere(int nu, double edge, int *V, int *F, double **points, fem_uint **tri) {
+  return fem::guarded("fem_make_icosphere", [&]() -> int {
   fem::SimpleTriMesh m;
   int rc = fem::makeIcosphere(nu, edge, m);
   if (rc != FEM_OK) return fail(rc, "fem_make_icosphere: need 1 <= nu <= 4000, edge > 0");
   return exportMesh(m, V, F, points, tri);
+  });
 }
 
 int fem_make_scanned_like(int nu, double edge, fem_uint seed, double flip_fraction, double noise_amp,
                           double high_valence_fraction, int high_valence, int *V, int *F, double **points,
                           fem_uint **tri) {
+  return fem::guarded("fem_make_scanned_like", [&]() -> int {
   fem::SimpleTriMesh m;
   int rc = fem::makeScannedLike(nu, edge, seed, flip_fraction, noise_amp, high_valence_fraction, high_valence, m);
   if (rc != FEM_OK) return fail(rc, "fem_make_scanned_like: bad argument");
   return exportMesh(m, V, F, points, tri);
+  });
 }
 
 int fem_make_strip(int nx, int ny, double h, int *V, int *F, double **points, fem_uint **tri) {
+  return fem::guarded("fem_make_strip", [&]() -> int {
   fem::SimpleTriMesh m;
   int rc = fem::makeStrip(nx, ny, h, m);
   if (rc != FEM_OK) return fail(rc, "fem_make_strip: need nx, ny >= 2, h > 0");
   return exportMesh(m, V, F, points, tri);
+  });
 }
 
 int fem_subdivide(int V, int F, const double *points, const fem_uint *tri, int levels, int *Vout, int *Fout,
                   double **points_out, fem_uint **tri_out) {
+  return fem::guarded("fem_subdivide", [&]() -> int {
   if (V < 0 || F < 0 || (V && !points) || (F && !tri)) return fail(FEM_ERR_INVALID, "fem_subdivide: bad argument");
   fem::SimpleTriMesh in, out;
   in.points.assign(points, points + 3 * (size_t)V);
@@ -105,6 +118,7 @@ int fem_subdivide(int V, int F, const double *points, const fem_uint *tri, int l
   int rc = fem::subdivide(in, levels, out);
   if (rc != FEM_OK) return fail(rc, "fem_subdivide: 0 <= levels <= 12, manifold input, result below 2^32 vertices");
   return exportMesh(out, Vout, Fout, points_out, tri_out);
+  });
 }
 
 void fem_initial_condition(int V, fem_uint seed, double nMax, double *nFn, double *cFn) {
@@ -114,6 +128,7 @@ void fem_initial_condition(int V, fem_uint seed, double nMax, double *nFn, doubl
 // ---- mesh handle -------------------------------------------------------------
 
 int fem_mesh_create(int V, int F, const double *points, const fem_uint *tri, fem_mesh **out) {
+  return fem::guarded("fem_mesh_create", [&]() -> int {
   if (V <= 0 || F < 0 || !points || (F && !tri) || !out) return fail(FEM_ERR_INVALID, "fem_mesh_create: bad argument");
   fem_mesh *m = new (std::nothrow) fem_mesh();
   if (!m) return fail(FEM_ERR_ALLOC, "out of memory");
@@ -123,6 +138,7 @@ int fem_mesh_create(int V, int F, const double *points, const fem_uint *tri, fem
   if (rc != FEM_OK) { delete m; return fail(rc, "fem_mesh_create: bad connectivity"); }
   *out = m;
   return FEM_OK;
+  });
 }
 
 void fem_mesh_destroy(fem_mesh *m) { delete m; }
@@ -152,20 +168,25 @@ void fem_mesh_topology(const fem_mesh *m, const int32_t **opp, const fem_uint **
 // ---- partition -----------------------------------------------------------------
 
 int fem_partition_vertices(const fem_mesh *m, int n, int64_t *npart) {
+  return fem::guarded("fem_partition_vertices", [&]() -> int {
   if (!m || !npart) return fail(FEM_ERR_INVALID, "fem_partition_vertices: null");
   int rc = fem::partitionVertices(m->mesh, n, npart);
   return rc == FEM_OK ? rc : fail(rc, "fem_partition_vertices: need 1 <= n <= V");
+  });
 }
 
 int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart) {
+  return fem::guarded("fem_partition_vertices_graph", [&]() -> int {
   if (!m || !npart) return fail(FEM_ERR_INVALID, "fem_partition_vertices_graph: null");
   int rc = fem::partitionVerticesGraph(m->mesh, n, npart);
   return rc == FEM_OK ? rc : fail(rc, "fem_partition_vertices_graph: need 1 <= n <= V and a mesh with topology");
+  });
 }
 
 int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,
                         int64_t *perm_f, fem_uint *node_parts, fem_uint *element_parts,
                         fem_mesh **ordered) {
+  return fem::guarded("fem_partition_apply", [&]() -> int {
   if (!original || !npart || !perm_v || !perm_f || !node_parts || !element_parts || n < 1)
     return fail(FEM_ERR_INVALID, "fem_partition_apply: bad argument");
   const fem::SimpleTriMesh &om = original->mesh;
@@ -186,39 +207,47 @@ int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, i
     *ordered = o;
   }
   return (int)(cut > 0x7fffffff ? 0x7fffffff : cut);
+  });
 }
 
 int fem_partition(const fem_mesh *original, int n, int64_t *perm_v, int64_t *perm_f,
                   fem_uint *node_parts, fem_uint *element_parts, fem_mesh **ordered) {
+  return fem::guarded("fem_partition", [&]() -> int {
   if (!original || !perm_v) return fail(FEM_ERR_INVALID, "fem_partition: null");
   std::vector<int64_t> npart(original->mesh.n_vertices());
   int rc = fem_partition_vertices(original, n, npart.data());
   if (rc != FEM_OK) return rc;
   return fem_partition_apply(original, n, npart.data(), perm_v, perm_f, node_parts, element_parts, ordered);
+  });
 }
 
 // ---- assembly + CPU operators ------------------------------------------------------
 
 int fem_mesh_init_stats(fem_mesh *m, int precision) {
+  return fem::guarded("fem_mesh_init_stats", [&]() -> int {
   if (!m || (precision != FEM_PREC_MIXED && precision != FEM_PREC_F64))
     return fail(FEM_ERR_INVALID, "fem_mesh_init_stats: precision must be FEM_PREC_MIXED or FEM_PREC_F64");
   fem::initMeshStats(m->mesh, m->stats, precision);
   return FEM_OK;
+  });
 }
 
 int fem_mesh_init_stats_shard(fem_mesh *m, int precision, const fem_shard *shard) {
+  return fem::guarded("fem_mesh_init_stats_shard", [&]() -> int {
   if (!m || !shard || (precision != FEM_PREC_MIXED && precision != FEM_PREC_F64))
     return fail(FEM_ERR_INVALID, "fem_mesh_init_stats_shard: bad argument");
   for (fem::uint v : shard->s.loc2glob)
     if (v >= m->mesh.n_vertices()) return fail(FEM_ERR_INVALID, "fem_mesh_init_stats_shard: the shard is not a shard of this mesh");
   fem::initMeshStatsRows(m->mesh, m->stats, precision, shard->s.loc2glob);
   return FEM_OK;
+  });
 }
 
 int fem_mesh_stats(const fem_mesh *m, const double **meshAngle, const double **meshCot,
                    const double **meshArea, const double **areaPerVtx, const double **wHej,
                    const double **wVtx, double *maxEdgeLen, const double **gradVec12,
                    const double **gradVec13) {
+  return fem::guarded("fem_mesh_stats", [&]() -> int {
   if (!m || m->stats.precision < 0) return fail(FEM_ERR_INVALID, "fem_mesh_stats: stats not initialised");
   const fem::MeshStats &s = m->stats;
   if (meshAngle) *meshAngle = s.meshAngle.data();
@@ -231,30 +260,38 @@ int fem_mesh_stats(const fem_mesh *m, const double **meshAngle, const double **m
   if (gradVec12) *gradVec12 = s.gradVec12.data();
   if (gradVec13) *gradVec13 = s.gradVec13.data();
   return FEM_OK;
+  });
 }
 
 int fem_compute_laplacian_cpu(const fem_mesh *m, const double *fn, double *lap) {
+  return fem::guarded("fem_compute_laplacian_cpu", [&]() -> int {
   if (!m || m->stats.precision < 0 || !fn || !lap) return fail(FEM_ERR_INVALID, "fem_compute_laplacian_cpu: bad argument");
   fem::computeLaplacianCPU(m->mesh, fn, lap, m->stats.wHej.data(), m->stats.wVtx.data());
   return FEM_OK;
+  });
 }
 
 int fem_compute_face_gradients_cpu(const fem_mesh *m, const double *fn, double *faceGrad) {
+  return fem::guarded("fem_compute_face_gradients_cpu", [&]() -> int {
   if (!m || m->stats.precision < 0 || !fn || !faceGrad) return fail(FEM_ERR_INVALID, "fem_compute_face_gradients_cpu: bad argument");
   fem::computeFaceGradientsCPU(m->mesh, m->stats.gradVec12.data(), m->stats.gradVec13.data(), faceGrad, fn, m->stats.precision);
   return FEM_OK;
+  });
 }
 
 int fem_compute_vertex_gradients_cpu(const fem_mesh *m, const double *faceGrad, double *vtxGrad) {
+  return fem::guarded("fem_compute_vertex_gradients_cpu", [&]() -> int {
   if (!m || m->stats.precision < 0 || !faceGrad || !vtxGrad) return fail(FEM_ERR_INVALID, "fem_compute_vertex_gradients_cpu: bad argument");
   fem::computeVertexGradientsCPU(m->mesh, faceGrad, vtxGrad, m->stats.meshAngle.data(), m->stats.precision);
   return FEM_OK;
+  });
 }
 
 // ---- reference layout ------------------------------------------------------------------
 
 int fem_ref_layout_create(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                           const fem_uint *element_parts, fem_ref_layout **out) {
+  return fem::guarded("fem_ref_layout_create", [&]() -> int {
   if (!ordered || !node_parts || !element_parts || !out) return fail(FEM_ERR_INVALID, "fem_ref_layout_create: null");
   fem_ref_layout *l = new (std::nothrow) fem_ref_layout();
   if (!l) return fail(FEM_ERR_ALLOC, "out of memory");
@@ -262,6 +299,7 @@ int fem_ref_layout_create(const fem_mesh *ordered, int n, const fem_uint *node_p
   if (rc != FEM_OK) { delete l; return fail(rc, "fem_ref_layout_create: stats missing or part arrays inconsistent"); }
   *out = l;
   return FEM_OK;
+  });
 }
 
 void fem_ref_layout_destroy(fem_ref_layout *l) { delete l; }
@@ -294,6 +332,7 @@ void fem_ref_layout_arrays(const fem_ref_layout *l, const fem_uint **halo_faces_
 
 int fem_shard_create(const fem_mesh *ordered, int n, const fem_uint *node_parts, int rank, int nranks,
                      int krings, fem_shard **out) {
+  return fem::guarded("fem_shard_create", [&]() -> int {
   if (!ordered || !node_parts || !out) return fail(FEM_ERR_INVALID, "fem_shard_create: null");
   fem_shard *s = new (std::nothrow) fem_shard();
   if (!s) return fail(FEM_ERR_ALLOC, "out of memory");
@@ -301,6 +340,7 @@ int fem_shard_create(const fem_mesh *ordered, int n, const fem_uint *node_parts,
   if (rc != FEM_OK) { delete s; return fail(rc, "fem_shard_create: need 1 <= nranks <= n, 0 <= rank < nranks, krings >= 1"); }
   *out = s;
   return FEM_OK;
+  });
 }
 
 void fem_shard_destroy(fem_shard *s) { delete s; }

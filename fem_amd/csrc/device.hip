@@ -72,8 +72,9 @@ size_t pitchFor(size_t widthBytes) { return (widthBytes + 511) / 512 * 512; }   
 // ===========================================================================
 
 // Register-tile geometries of the fused kernel: threads per workgroup, rows per thread, minimum
-// waves per SIMD (sets the VGPR budget: 4 -> 128, 3 -> 168).  FEM_TILE_CONFIG picks one (tuning knob;
-// 0 = 512 x 2 is the measured best: no spills, 2 workgroups per CU, 1024 register-resident rows per tile).
+// waves per SIMD (sets the VGPR budget: 4 -> 128, 3 -> 168).  FEM_TILE_CONFIG picks one (tuning knob); the
+// defaults below are the measured best: 8 = 512 x 4 (2048 register-resident rows per tile, 128 VGPRs, 2 workgroups
+// per CU) for large meshes without rows wider than 6 entries, 2 = 512 x 3 otherwise.
 constexpr int kTileW = 6;
 constexpr fem_uint kTileMaxLocal = 4096;
 constexpr fem_uint kTileMaxExtra = 1536;  // LDS-resident overflow entries per tile (rows with more than kTileW neighbours)
@@ -121,7 +122,7 @@ struct fem_plan {
   void *pos = nullptr, *pos0 = nullptr, *rec = nullptr;      // T4[Vg], T4[Vg], T4[4F]
   double *maxedge = nullptr, *blockmax = nullptr;
   // semi-implicit stepping (FEM_PLAN_IMPLICIT): lumped mass and row sums of w per row; CG work vectors
-  bool can_imex = false;
+  bool can_imex = false, imex_ready = false;
   void *mass = nullptr, *wsum = nullptr, *ix_w = nullptr, *ix_r = nullptr, *ix_p = nullptr, *ix_q = nullptr;
   double *ix_partial = nullptr, *ix_sc = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
@@ -253,16 +254,24 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
   typedef typename Vec<T>::t4 T4;
   const size_t V = p->V;
   const fem_uint nbv = (fem_uint)((V + 255) / 256), nbs = p->nblocks;
-  if (!p->ix_r) {
-    HIP_TRY(hipMalloc(&p->ix_r, sizeof(T2) * V));
-    HIP_TRY(hipMalloc(&p->ix_p, sizeof(T2) * V));
-    HIP_TRY(hipMalloc(&p->ix_q, sizeof(T2) * V));
-    HIP_TRY(hipMalloc((void **)&p->ix_partial, 16 * (size_t)std::max(nbv, nbs)));
-    HIP_TRY(hipMalloc((void **)&p->ix_sc, 16 * sizeof(double)));
-    HIP_TRY(hipMemset(p->ix_sc, 0, 16 * sizeof(double)));
-    HIP_TRY(hipMalloc(&p->ix_w, sizeof(T) * (p->entries ? p->entries : 1)));
-    hipLaunchKernelGGL(imex_weights_kernel<T>, dim3((unsigned)((p->entries + 255) / 256)), dim3(256), 0, st, (const T4 *)p->coef,
-                       (T *)p->ix_w, p->entries);
+  if (!p->imex_ready) {
+    // work vectors: allocated into locals and committed to the plan only when every one of them exists and the
+    // weights have been extracted, so that a failed allocation leaves nothing half set up for the next call
+    void *bufs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t sizes[6] = {sizeof(T2) * V, sizeof(T2) * V, sizeof(T2) * V, 16 * (size_t)std::max(nbv, nbs), 16 * sizeof(double),
+                             sizeof(T) * (p->entries ? p->entries : 1)};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 6 && e == hipSuccess; i++) e = hipMalloc(&bufs[i], sizes[i] ? sizes[i] : 1);
+    if (e == hipSuccess) e = hipMemsetAsync(bufs[4], 0, sizes[4], st);
+    if (e != hipSuccess) {
+      for (void *q : bufs) if (q) (void)hipFree(q);
+      return fail(FEM_ERR_DEVICE, "fem_plan_run_imex: work vectors", e);
+    }
+    p->ix_r = bufs[0]; p->ix_p = bufs[1]; p->ix_q = bufs[2]; p->ix_partial = (double *)bufs[3]; p->ix_sc = (double *)bufs[4]; p->ix_w = bufs[5];
+    if (p->entries > 0)
+      hipLaunchKernelGGL(imex_weights_kernel<T>, dim3((unsigned)((p->entries + 255) / 256)), dim3(256), 0, st, (const T4 *)p->coef,
+                         (T *)p->ix_w, p->entries);
+    p->imex_ready = true;
   }
   const ModelT<T> m = {(T)(model->nMax - p->base_n), (T)model->D, (T)model->r, (T)model->alpha, (T)model->S, (T)dt, (T)p->base_n,
                        (T)(1.0 / (1.0 + p->base_n))};
@@ -337,9 +346,13 @@ int fem_step(fem_double2 *fn_src, fem_double2 *fn_dst, fem_uint *fv, double *fv_
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   ModelD m = {model->nMax, model->D, model->r, model->alpha, model->S};
+  // FEM_REF_SORT=0 (measurement only): the corner lists are summed in the order the atomics filled them -- what the
+  // sort costs is the difference (profiles/README.md r02: nothing measurable); results are then order-dependent
+  static const bool sorted = !(getenv("FEM_REF_SORT") && !strcmp(getenv("FEM_REF_SORT"), "0"));
+  auto kern = sorted ? ref_step_kernel<true> : ref_step_kernel<false>;
   if (lds > 64 * 1024)
-    HIP_TRY(hipFuncSetAttribute((const void *)ref_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(ref_step_kernel, dim3(blocks), dim3(256), lds, (hipStream_t)stream,
+    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, (hipStream_t)stream,
                      (const double2 *)fn_src, (double2 *)fn_dst, fv, fv_weights,
                      fv_pitchInBytes / (fem_uint)sizeof(fem_uint), fvw_pitchInBytes / (fem_uint)sizeof(double),
                      nbr, vtxW, vw_pitchInBytes / (fem_uint)sizeof(double), vertex_weights,
@@ -385,6 +398,7 @@ static hipError_t upload2D(void **dev, size_t *pitch, const void *host, size_t w
 }
 
 int fem_ref_device_create(const fem_ref_layout *lay, const fem_uint *node_parts, int V, fem_ref_device **out) {
+  return fem::guarded("fem_ref_device_create", [&]() -> int {
   if (!lay || !node_parts || !out || V <= 0) return fail(FEM_ERR_INVALID, "fem_ref_device_create: bad argument");
   const fem::RefLayout &l = lay->l;
   // limits of GPUrun, main.cpp:357-364 (<= 1024 vertices and faces per partition)
@@ -412,6 +426,7 @@ int fem_ref_device_create(const fem_ref_layout *lay, const fem_uint *node_parts,
   if (e != hipSuccess) { fem_ref_device_destroy(d); return fail(FEM_ERR_DEVICE, "fem_ref_device_create", e); }
   *out = d;
   return FEM_OK;
+  });
 }
 
 int fem_ref_device_set_state(fem_ref_device *d, const fem_double2 *fn) {
@@ -630,29 +645,37 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
 }
 
 int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *model, fem_plan **out) {
+  return fem::guarded("fem_plan_create", [&]() -> int {
   return planCreate(ordered, nullptr, precision, model, 0, 0, nullptr, 0, out);
+  });
 }
 
 int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts, const fem_shard *shard,
                        int precision, const fem_model *model, int ksteps, unsigned flags, fem_plan **out) {
+  return fem::guarded("fem_plan_create_ex", [&]() -> int {
   int rc = planCreate(ordered, shard ? &shard->s : nullptr, precision, model, ksteps, n, node_parts, flags, out);
   if (rc == FEM_OK && (flags & FEM_PLAN_DEVICE_ASSEMBLY)) {
     rc = fem_plan_set_points(*out, ordered->mesh.points.data());
     if (rc != FEM_OK) { fem_plan_destroy(*out); *out = nullptr; }
   }
   return rc;
+  });
 }
 
 int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts, const fem_shard *shard,
                           int precision, const fem_model *model, int ksteps, fem_plan **out) {
+  return fem::guarded("fem_plan_create_tiled", [&]() -> int {
   if (ksteps < 1) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: ksteps must be 1..8");
   return planCreate(ordered, shard ? &shard->s : nullptr, precision, model, ksteps, n, node_parts, 0, out);
+  });
 }
 
 int fem_plan_create_shard(const fem_mesh *ordered, const fem_shard *shard, int precision, const fem_model *model,
                           fem_plan **out) {
+  return fem::guarded("fem_plan_create_shard", [&]() -> int {
   if (!shard) return fail(FEM_ERR_INVALID, "fem_plan_create_shard: null shard");
   return planCreate(ordered, &shard->s, precision, model, 0, 0, nullptr, 0, out);
+  });
 }
 
 int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream) { return fem_plan_pack_halo_from(p, 0, dst_dev, stream); }
@@ -680,6 +703,7 @@ int fem_plan_pack_halo_from(fem_plan *p, int which, uint64_t dst_dev, void *stre
 }
 
 int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn) {
+  return fem::guarded("fem_plan_set_state", [&]() -> int {
   if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_set_state: null");
   HIP_TRY(hipDeviceSynchronize());
   if (p->precision == FEM_PREC_F32) {
@@ -692,9 +716,11 @@ int fem_plan_set_state(fem_plan *p, const double *nFn, const double *cFn) {
     HIP_TRY(hipMemcpy(p->state[p->cur], h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
   }
   return FEM_OK;
+  });
 }
 
 int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn) {
+  return fem::guarded("fem_plan_get_state", [&]() -> int {
   if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_get_state: null");
   HIP_TRY(hipDeviceSynchronize());
   if (p->precision == FEM_PREC_F32) {
@@ -707,6 +733,7 @@ int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn) {
     for (size_t i = 0; i < p->V; i++) { nFn[i] = p->base_n + h[2 * i]; cFn[i] = p->base_c + h[2 * i + 1]; }
   }
   return FEM_OK;
+  });
 }
 
 static int launchTiles(fem_plan *p, fem_uint first, fem_uint count, int nsteps, double dt, const fem_model *model,
@@ -794,12 +821,14 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
 // ---- semi-implicit stepping (runImex above) ---------------------------------------------------
 
 int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream) {
+  return fem::guarded("fem_plan_run_imex", [&]() -> int {
   if (!p || nsteps < 0 || cg_iterations < 1 || cg_iterations > 10000) return fail(FEM_ERR_INVALID, "fem_plan_run_imex: bad argument");
   if (!p->can_imex) return fail(FEM_ERR_INVALID, "fem_plan_run_imex: plan was not created with FEM_PLAN_IMPLICIT");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   return p->precision == FEM_PREC_F32 ? runImex<float>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream)
                                       : runImex<double>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream);
+  });
 }
 
 int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c) {
@@ -827,8 +856,10 @@ int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, i
 // ---- device assembly -----------------------------------------------------------------------------
 
 int fem_plan_set_points(fem_plan *p, const double *points) {
+  return fem::guarded("fem_plan_set_points", [&]() -> int {
   if (!p || !points || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_set_points: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
   return p->precision == FEM_PREC_F32 ? setPoints<float>(p, points) : setPoints<double>(p, points);
+  });
 }
 
 int fem_plan_assemble(fem_plan *p, void *stream) {
@@ -876,10 +907,12 @@ int fem_plan_max_edge(fem_plan *p, double *maxEdgeLen) {
 }
 
 int fem_plan_face_records(fem_plan *p, double *rec16F) {
+  return fem::guarded("fem_plan_face_records", [&]() -> int {
   if (!p || !p->can_assemble || !rec16F) return fail(FEM_ERR_INVALID, "fem_plan_face_records: bad argument");
   HIP_TRY(p->precision == FEM_PREC_F32 ? launchFaceRecords<float>(p) : launchFaceRecords<double>(p));
   return p->precision == FEM_PREC_F32 ? downloadAs<float>(p->rec, 16 * (size_t)p->F, rec16F)
                                       : downloadAs<double>(p->rec, 16 * (size_t)p->F, rec16F);
+  });
 }
 
 uint64_t fem_plan_coef_count(const fem_plan *p) {
@@ -888,16 +921,19 @@ uint64_t fem_plan_coef_count(const fem_plan *p) {
 }
 
 int fem_plan_download_coef(fem_plan *p, double *out) {
+  return fem::guarded("fem_plan_download_coef", [&]() -> int {
   if (!p || !out) return fail(FEM_ERR_INVALID, "fem_plan_download_coef: null");
   const void *dev = p->ksteps > 0 ? p->tcoef : p->coef;
   const size_t n = fem_plan_coef_count(p);
   return p->precision == FEM_PREC_F32 ? downloadAs<float>(dev, n, out) : downloadAs<double>(dev, n, out);
+  });
 }
 
 
 // ---- result output ------------------------------------------------------------------------------------
 
 int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *rgb, double *nmin, double *nmax) {
+  return fem::guarded("fem_plan_format", [&]() -> int {
   if (!p || nverts == 0 || nverts > p->V) return fail(FEM_ERR_INVALID, "fem_plan_format: bad vertex count");
   const fem_uint V = nverts, nb = std::min<fem_uint>((V + 255) / 256, 1024);
   double *part = nullptr, *mm = nullptr;
@@ -928,11 +964,12 @@ int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *r
     for (size_t i = 0; i < V; i++)
       for (int k = 0; k < 3; k++) {
         const double c = 255.0 * h[4 * i + k];
-        rgb[3 * i + k] = (unsigned char)(c < 0 ? 0 : (c > 255 ? 255 : c));
+        rgb[3 * i + k] = (unsigned char)(c > 0 ? (c > 255 ? 255 : c) : 0);      // NaN and negatives -> 0
       }
   if (nmin) *nmin = hmm[0] + p->base_n;     // the buffers hold deviations from base_n
   if (nmax) *nmax = hmm[1] + p->base_n;
   return FEM_OK;
+  });
 }
 
 // ---- result output without allocation ---------------------------------------------------------------

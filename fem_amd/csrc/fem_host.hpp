@@ -4,6 +4,8 @@
 #pragma once
 
 #include <cstdint>
+#include <exception>
+#include <new>
 #include <string>
 #include <thread>
 #include <utility>
@@ -87,12 +89,27 @@ template <typename Fn> void parallelFor(size_t n, size_t grain, Fn fn) {
   const int T = n >= grain ? hostThreads() : 1;
   if (T <= 1) { fn((size_t)0, n); return; }
   std::vector<std::thread> th;
-  for (int t = 0; t < T; t++) th.emplace_back([=]() { fn(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); });
+  std::vector<std::exception_ptr> err((size_t)T);          // an exception in a worker (bad_alloc ...) is rethrown by the caller
+  for (int t = 0; t < T; t++)
+    th.emplace_back([=, &err]() {
+      try { fn(n * (size_t)t / (size_t)T, n * (size_t)(t + 1) / (size_t)T); }
+      catch (...) { err[(size_t)t] = std::current_exception(); }
+    });
   for (auto &x : th) x.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
 // records status + message for fem_last_error()/fem_error_detail(); returns status
 int fail(int status, const char *what);
+
+// Body of an extern "C" entry point that allocates on the host: no exception crosses the C boundary
+// (fem_hip.h: "none aborts") -- out of memory becomes FEM_ERR_ALLOC, anything else FEM_ERR_INVALID.
+template <typename Fn> int guarded(const char *where, Fn fn) {
+  try { return fn(); }
+  catch (const std::bad_alloc &) { return fail(FEM_ERR_ALLOC, where); }
+  catch (const std::exception &e) { return fail(FEM_ERR_INVALID, e.what()); }
+  catch (...) { return fail(FEM_ERR_INVALID, where); }
+}
 
 }  // namespace fem
 

@@ -19,6 +19,7 @@
 // consecutive runs.
 // LDS: cur[size], ent[size*vv_size] uint; fg[6*fpitch] float  (4*size*(1 + vv_size) + 24*fpitch B).
 // ---------------------------------------------------------------------------
+template <bool SORT>
 __global__ __launch_bounds__(256) void ref_step_kernel(
     const double2 *__restrict__ fn_src, double2 *__restrict__ fn_dst, const uint *__restrict__ fv,
     const double *__restrict__ fv_weights, uint fv_pitch, uint fvw_pitch, const uint *__restrict__ nbr,
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
     // this vertex's corners in ascending (face slot, corner) order: weighted gradient sums in float,
     // weight sum in double (FEM_common.cu:118-132), then the normalised dot product (:153-158)
     const uint eb = t * vv_size, ee = eb + min(s_cur[t], vv_size);
-    for (uint i = eb + 1; i < ee; i++) {              // insertion sort, a handful of entries
+    for (uint i = eb + 1; SORT && i < ee; i++) {      // insertion sort, a handful of entries
       const uint key = s_ent[i];
       uint k = i;
       while (k > eb && s_ent[k - 1] > key) { s_ent[k] = s_ent[k - 1]; k--; }

@@ -288,6 +288,9 @@ int readOFF(const std::string &path, SimpleTriMesh &m) {
   long nv, nf, ne;
   if (!c.integer(nv) || !c.integer(nf) || !c.integer(ne) || nv < 0 || nf < 0) return FEM_ERR_IO;
   if (nv > 0xfffffff0l || nf > 0xfffffff0l) return FEM_ERR_LIMIT;
+  // a vertex record is at least "0 0 0\n" (6 bytes), a face record at least "3 0 1 2\n" (8): counts the file
+  // cannot hold are refused before anything is sized from them
+  if ((size_t)nv * 6 + (size_t)nf * 8 > file.size + 2) return FEM_ERR_IO;
   m.clean();
   m.points.resize(3 * (size_t)nv);
   if (hasColor) m.colors.resize(3 * (size_t)nv);
@@ -332,6 +335,7 @@ int readOFF(const std::string &path, SimpleTriMesh &m) {
       std::vector<std::thread> th;
       for (int t = 0; t < T; t++)
         th.emplace_back([&, t]() {
+          try {
           long rec = count[t];
           std::vector<long> poly;
           const long myFaces = count[t + 1] - std::max(count[t], nv);
@@ -350,6 +354,7 @@ int readOFF(const std::string &path, SimpleTriMesh &m) {
             }
             q = next;
           }
+          } catch (...) { ok[t] = 0; }                   // out of memory in a worker: the sequential parser decides (and reports)
         });
       for (auto &x : th) x.join();
       lap("parse");
@@ -475,12 +480,14 @@ int readPLY(const std::string &path, SimpleTriMesh &m) {
     }
     if (isV) {
       if (ix < 0 || iy < 0 || iz < 0 || el.count > 0xfffffff0l) return FEM_ERR_IO;
+      if ((size_t)el.count * (ascii ? 6 : 3) > (size_t)(end - cur.p) + 2) return FEM_ERR_IO;   // more vertices than the file can hold
       nv = el.count;
       m.points.resize(3 * (size_t)nv);
       const bool col = ir >= 0 && ig >= 0 && ib >= 0;
       if (col) m.colors.resize(3 * (size_t)nv);
     }
     if (isF && (il < 0 || nv < 0)) return FEM_ERR_IO;
+    if (isF && (el.count < 0 || (size_t)el.count * (ascii ? 8 : 4) > (size_t)(end - cur.p) + 2)) return FEM_ERR_IO;   // likewise
     if (isF) m.faces.reserve(3 * (size_t)el.count);
     for (long i = 0; i < el.count; i++)
       for (size_t k = 0; k < el.props.size(); k++) {

@@ -242,9 +242,10 @@ int fem_plan_create(const fem_mesh *ordered, int precision, const fem_model *mod
 /* Same operator in the fused-tile layout: every workgroup stages one partition (+ ksteps rings
  * of neighbours) in LDS, keeps its operator rows in registers and takes up to `ksteps` time
  * steps per launch (fused multi-step kernel; 1 <= ksteps <= 8).  n/node_parts = the partition
- * ranges of the ordered mesh (partitioning_common.h:3-9 outputs); shard may be NULL.  Fails with
- * FEM_ERR_LIMIT on meshes with a vertex of valence > 6 (use fem_plan_create there).
- * fem_plan_run on such a plan issues ceil(nsteps / ksteps) launches. */
+ * ranges of the ordered mesh (partitioning_common.h:3-9 outputs); shard may be NULL.  Rows of more than 6
+ * neighbours keep their first 6 entries in the register tile and the rest in LDS (up to 1536 such entries per
+ * tile); partitions that do not fit a tile are split.  FEM_ERR_LIMIT only when a tile cannot be made to fit
+ * (a vertex of valence > 1536).  fem_plan_run on such a plan issues ceil(nsteps / ksteps) launches. */
 int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                           const fem_shard *shard, int precision, const fem_model *model,
                           int ksteps, fem_plan **out);

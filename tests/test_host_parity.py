@@ -413,3 +413,21 @@ def test_shard_restricted_assembly_rows_are_bit_identical():
         rows = np.isin(om.topology()["he_from"], l2g)
         assert np.array_equal(full["wHej"][rows], loc["wHej"][rows]) and (loc["wHej"][~rows] == 0).all()
         assert loc["maxEdgeLen"] == full["maxEdgeLen"]
+
+
+def test_readers_refuse_counts_the_file_cannot_hold(tmp_path):
+    """a header that promises billions of records in a few bytes is an IO error, not an allocation of that size
+    (fem_hip.h: no entry point aborts)"""
+    off = tmp_path / "liar.off"
+    off.write_text("OFF\n4000000000 4000000000 0\n0 0 0\n")
+    with pytest.raises(fa.FemError):
+        fa.off_read(str(off))
+    ply = tmp_path / "liar.ply"
+    ply.write_bytes(b"ply\nformat binary_little_endian 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                    b"element face 2000000000\nproperty list uchar int vertex_indices\nend_header\n" + b"\0" * 36)
+    with pytest.raises(fa.FemError):
+        fa.ply_read(str(ply))
+    ply.write_bytes(b"ply\nformat ascii 1.0\nelement vertex 3000000000\nproperty float x\nproperty float y\nproperty float z\n"
+                    b"element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n")
+    with pytest.raises(fa.FemError):
+        fa.ply_read(str(ply))
