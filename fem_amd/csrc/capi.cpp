@@ -183,6 +183,18 @@ int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart) {
   });
 }
 
+int fem_partition_vertices_multilevel(const fem_mesh *m, int n, int64_t *npart, int64_t *epart, int64_t *dual_cut) {
+  return fem::guarded("fem_partition_vertices_multilevel", [&]() -> int {
+  if (!m || !npart) return fail(FEM_ERR_INVALID, "fem_partition_vertices_multilevel: null");
+  std::vector<int64_t> ep;
+  if (!epart && dual_cut) { ep.resize(m->mesh.n_faces()); epart = ep.data(); }
+  int rc = fem::partitionVerticesMultilevel(m->mesh, n, npart, epart);
+  if (rc != FEM_OK) return fail(rc, "fem_partition_vertices_multilevel: need 1 <= n <= F and a mesh with topology");
+  if (dual_cut) *dual_cut = fem::dualEdgeCut(m->mesh, epart);
+  return FEM_OK;
+  });
+}
+
 int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,
                         int64_t *perm_f, fem_uint *node_parts, fem_uint *element_parts,
                         fem_mesh **ordered) {

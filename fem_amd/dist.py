@@ -11,6 +11,12 @@ import fem_amd as fa
 _PROFILES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 
 
+def _partition(mesh, nparts):
+    """R0 stage by FEM_PARTITIONER: rcb (default; exactly equal parts, lowest cut on the surfaces measured), graph,
+    multilevel (METIS_PartMeshDual-style: multilevel k-way on the dual graph)"""
+    return mesh.partition(nparts, method=os.environ.get("FEM_PARTITIONER", "rcb"))
+
+
 def _time_step(om, model, rule):
     """"reference": dt = 0.1 maxEdgeLen^2 (main.cpp:188; assumes near-uniform triangles);
     "stable": inside the explicit diffusion limit of the assembled operator (irregular meshes)"""
@@ -25,7 +31,7 @@ class SingleRun:
     def __init__(self, mesh, nparts, precision="f32", seed=1, ksteps=0, dt_rule="reference"):
         self.ksteps = ksteps
         self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
-        self.part = mesh.partition(nparts)
+        self.part = _partition(mesh, nparts)
         om = self.part.ordered
         om.init_stats(fa.PREC_F64)
         self.model = fa.default_model()
@@ -71,7 +77,7 @@ class DeformRun:
     def __init__(self, mesh, nparts, precision="f32", seed=1, fused=True):
         self.kernel_name = "assemble_step_sell_kernel" if fused else "assemble_rows_sell_kernel"
         self.fused = fused
-        self.part = mesh.partition(nparts)
+        self.part = _partition(mesh, nparts)
         om = self.part.ordered
         om.init_stats(fa.PREC_F64)
         self.model = fa.default_model()
@@ -222,7 +228,7 @@ class ShardedRun:
         self.steps_per_launch = max(1, ksteps)
         # the partition is shared (deterministic: every rank computes the same one); everything after it is
         # rank-local: the shard, then the assembly of the rows of the shard's local vertices only
-        self.part = mesh.partition(nparts)
+        self.part = _partition(mesh, nparts)
         om = self.part.ordered
         self.model = fa.default_model()
         self.precision = precision

@@ -161,6 +161,14 @@ int fem_partition_vertices(const fem_mesh *m, int n, int64_t *npart);
  * at most one), same hierarchical numbering, deterministic.  For surfaces where a coordinate
  * split makes disconnected parts (folds, thin sheets); feed the result to fem_partition_apply. */
 int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart);
+/* Same stage the way METIS_PartMeshDual does it (partitioning_common.cpp:51-58, ncommon = 2): multilevel k-way
+ * partition of the DUAL graph (elements adjacent across an edge) -- heavy-edge-matching coarsening, weighted
+ * coordinate bisection of the coarsest graph, greedy k-way boundary refinement at every level, part weights within
+ * 3 % of the mean (how the per-block caps of main.cpp:357-364 enter) -- then the node partition induced from it
+ * (a vertex goes where most of its faces are).  Deterministic.  epart[F] (element partition) and dual_cut (dual
+ * edges cut) are optional outputs.  Feed npart to fem_partition_apply.  METIS itself is absent and unpinned, so raw
+ * part ids cannot be compared with the original binary's; the contract after this stage is bit-exact. */
+int fem_partition_vertices_multilevel(const fem_mesh *m, int n, int64_t *npart, int64_t *epart, int64_t *dual_cut);
 /* The deterministic stage after it (partitioning_common.cpp:78-176), given any
  * npart[]: same outputs as fem_partition. */
 int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,

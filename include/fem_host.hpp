@@ -95,6 +95,10 @@ int partition(const SimpleTriMesh &originalMesh, SimpleTriMesh *orderedMesh, uin
 // pieces of the above (partitioning_common.cpp:32-176)
 int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart);          // coordinate bisection
 int partitionVerticesGraph(const SimpleTriMesh &m, int n, int64_t *npart);     // graph bisection (needs topology)
+// multilevel k-way on the dual graph (the METIS_PartMeshDual stage, partitioning_common.cpp:51-58; needs topology);
+// epart (optional, [F]) receives the element partition the node partition was induced from
+int partitionVerticesMultilevel(const SimpleTriMesh &m, int n, int64_t *npart, int64_t *epart = nullptr);
+int64_t dualEdgeCut(const SimpleTriMesh &m, const int64_t *epart);   // dual edges between different parts
 void faceParts(const SimpleTriMesh &m, const int64_t *npart, int n, int64_t *epart);
 int createOrderArray(uint *parts, int64_t *part, int64_t N, int n);
 void reorderMesh(const SimpleTriMesh &original, SimpleTriMesh *ordered, const int64_t *npart,

@@ -22,9 +22,9 @@ def smooth_ic(pts, nMax=1.0, amp=0.005):
 class Case:
     """a mesh, partitioned and reordered by the product, with the oracle's tables of the ORDERED mesh"""
 
-    def __init__(self, pts, tri, nparts, seed=1):
+    def __init__(self, pts, tri, nparts, seed=1, method="rcb"):
         self.orig = fa.Mesh(pts, tri)
-        self.part = self.orig.partition(nparts)
+        self.part = self.orig.partition(nparts, method=method)
         self.mesh = self.part.ordered
         self.pts, self.tri = self.mesh.points, self.mesh.tri
         self.V, self.F, self.n = self.mesh.V, self.mesh.F, nparts

@@ -492,3 +492,35 @@ def test_timed_configuration_vs_oracle(cfg, ksteps, prec, monkeypatch):
         tol = TOL_F64 if prec == "f64" else TOL_F32
         assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol, (regular, rel_l2(n_gpu, n_ref), rel_l2(c_gpu, c_ref))
         assert not np.array_equal(n_gpu, n0)
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_fused_plan_on_multilevel_partition(prec):
+    """the METIS-style R0 stage (multilevel k-way on the dual graph: parts of unequal size, some needing a split to
+    fit a tile) feeding the fused plan and the drop-in step, regular and irregular mesh, against the oracle"""
+    from helpers import Case
+    for (pts, tri), regular in ((fa.make_icosphere(56, 0.1), True), (fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01), False)):
+        case = Case(pts, tri, max(2, len(pts) // 800), method="multilevel")
+        sizes = np.diff(case.part.node_parts.astype(np.int64))
+        assert sizes.min() > 0 and sizes.max() > sizes.min()
+        case.mesh.init_stats(fa.PREC_F64)
+        st = case.ostats(ol.F64)
+        dt = case.dt if regular else min(case.dt, stable_dt(st, case.model))
+        n0, c0 = smooth_ic(case.pts)
+        if prec == "f32":
+            n0, c0 = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+        n_ref, c_ref = st.step(n0, c0, dt, 13, case.model.as_array())
+        plan = fa.Plan(case.mesh, fa.PREC_F64 if prec == "f64" else fa.PREC_F32, part=case.part, ksteps=5)
+        plan.set_state(n0, c0)
+        plan.run(13, dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        tol = TOL_F64 if prec == "f64" else TOL_F32
+        assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol
+    if prec == "f64":
+        case = Case(*fa.make_icosphere(24, 0.1), 24, method="multilevel")
+        lay, dev = _ref_device(case)
+        dev.set_state(case.n0, case.c0)
+        dev.run(4, case.dt, case.model)
+        n_gpu, c_gpu = dev.get_state()
+        n_ref, c_ref = case.ostats(ol.MIXED).step(case.n0, case.c0, case.dt, 4, case.model.as_array())
+        assert rel_l2(n_gpu, n_ref) <= TOL_REF and rel_l2(c_gpu, c_ref) <= TOL_REF

@@ -431,3 +431,39 @@ def test_readers_refuse_counts_the_file_cannot_hold(tmp_path):
                     b"element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n")
     with pytest.raises(fa.FemError):
         fa.ply_read(str(ply))
+
+
+def test_multilevel_dual_graph_partition():
+    """the METIS_PartMeshDual stage as a multilevel k-way partition of the dual graph: every part non-empty, sizes
+    within a few per cent of the mean (the per-block caps as a balance constraint), deterministic, the element
+    partition it was induced from is balanced and its dual cut is what dualEdgeCut counts, the cut is within 15 % of
+    the coordinate bisection's, and the deterministic stage after it (R1-R3) accepts the result"""
+    import ctypes as C
+    for (pts, tri), n in ((fa.make_icosphere(48, 0.1), 24), (fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01), 20),
+                          (fa.make_strip(11, 41, 0.1), 3)):
+        mesh = fa.Mesh(pts, tri)
+        npart = mesh.partition_vertices(n, "multilevel")
+        again = mesh.partition_vertices(n, "multilevel")
+        assert np.array_equal(npart, again)
+        sizes = np.bincount(npart, minlength=n)
+        assert sizes.min() > 0 and npart.min() == 0 and npart.max() == n - 1
+        assert sizes.max() <= 1.06 * mesh.V / n + 2 and sizes.min() >= 0.90 * mesh.V / n - 2
+        epart = np.empty(mesh.F, np.int64)
+        cut = C.c_int64()
+        fa._check(fa.lib.fem_partition_vertices_multilevel(mesh.h, n, npart.ctypes.data_as(fa.i64p), epart.ctypes.data_as(fa.i64p),
+                                                            C.byref(cut)))
+        fsz = np.bincount(epart, minlength=n)
+        assert fsz.min() > 0 and fsz.max() <= 1.04 * mesh.F / n + 2
+        # dual edges (elements sharing an edge: ncommon = 2) between different parts, counted independently
+        t = mesh.topology()
+        F3 = 3 * mesh.F
+        h = np.arange(F3)
+        ho = t["opp"][:F3]
+        inner = (ho > h) & (ho < F3)
+        assert int((epart[h[inner] // 3] != epart[ho[inner] // 3]).sum()) == cut.value
+        part_ml = mesh.partition(n, npart=npart)
+        part_rcb = mesh.partition(n)
+        assert part_ml.cut <= 1.15 * part_rcb.cut
+        assert part_ml.node_parts[-1] == mesh.V and np.array_equal(np.diff(part_ml.node_parts.astype(np.int64)), sizes)
+    with pytest.raises(fa.FemError):
+        fa.Mesh(*fa.make_icosphere(2, 0.1)).partition_vertices(100000, "multilevel")
