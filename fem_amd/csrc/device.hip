@@ -248,11 +248,30 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
 
 // ---- semi-implicit stepping ------------------------------------------------------------------------
 
+// comm != null: the plan is a shard's (rows [0, nOwn) owned, then ghosts): the dot products run over the owned rows and
+// are summed over the ranks by comm->allreduce_sum, and every vector a matrix product reads (the right-hand side, the
+// search directions) gets its ghost rows from their owners through comm->exchange first.  The iterates' ghost rows
+// need no exchange of their own: x += alpha p with exchanged p and the global alpha is the owner's arithmetic.
 template <typename T>
-static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, int iters, hipStream_t st) {
+static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, int iters, hipStream_t st,
+                   const fem_imex_comm *comm = nullptr, fem_uint nOwn = 0) {
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   const size_t V = p->V;
+  const fem_uint Vdot = comm ? nOwn : p->V;
+  auto reduce = [&](fem_uint nparts, int what) -> int {          // partial sums -> scalars (global ones on a shard)
+    if (!comm) {
+      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nparts, p->ix_sc, what);
+      return FEM_OK;
+    }
+    hipLaunchKernelGGL(imex_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nparts, p->ix_sc + 12);
+    const int rc = comm->allreduce_sum(comm->ctx, (uint64_t)(p->ix_sc + 12), 2, (void *)st);
+    if (rc != FEM_OK) return rc;
+    hipLaunchKernelGGL(imex_finish_kernel, dim3(1), dim3(64), 0, st, (const double *)(p->ix_sc + 12), p->ix_sc, what);
+    return FEM_OK;
+  };
+  auto ghosts = [&](void *vec) -> int { return comm ? comm->exchange(comm->ctx, (uint64_t)vec, (void *)st) : FEM_OK; };
+#define IMEX_TRY(call) do { const int rc_ = (call); if (rc_ != FEM_OK) return rc_; } while (0)
   const fem_uint nbv = (fem_uint)((V + 255) / 256), nbs = p->nblocks;
   if (!p->imex_ready) {
     // work vectors: allocated into locals and committed to the plan only when every one of them exists and the
@@ -283,24 +302,29 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
     // b = u + dt * (explicit terms); x0 = b
     hipLaunchKernelGGL((sell_step_kernel<T, true, true>), dim3(nbs), dim3(256), 0, st, u, x, p->slice_off.p, p->idx.p,
                        (const T4 *)p->coef, p->V, p->nslices, p->nblocks, m);
+    IMEX_TRY(ghosts(x));
     // r0 = M b - A b, p0 = r0 / diag, rz
     hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)x, (T2 *)p->ix_q, (T2 *)p->ix_r, (T2 *)p->ix_p,
-                       p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, p->nslices, p->nblocks, dtDn, dtDc, 1, p->ix_partial);
-    hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbs, p->ix_sc, 0);
+                       p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, Vdot, p->nslices, p->nblocks, dtDn, dtDc, 1, p->ix_partial);
+    IMEX_TRY(reduce(nbs, 0));
+    IMEX_TRY(ghosts(p->ix_p));
     for (int it = 0; it < iters; it++) {
       hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)p->ix_p, (T2 *)p->ix_q, (T2 *)nullptr, (T2 *)nullptr,
-                         p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, p->nslices, p->nblocks, dtDn, dtDc, 0, p->ix_partial);
-      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbs, p->ix_sc, 1);
+                         p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, Vdot, p->nslices, p->nblocks, dtDn, dtDc, 0, p->ix_partial);
+      IMEX_TRY(reduce(nbs, 1));
       hipLaunchKernelGGL(imex_update_kernel<T>, dim3(nbv), dim3(256), 0, st, x, (T2 *)p->ix_r, (const T2 *)p->ix_p, (const T2 *)p->ix_q,
-                         mass, wsum, p->V, dtDn, dtDc, (const double *)p->ix_sc, p->ix_partial);
-      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nbv, p->ix_sc, 2);
-      if (it + 1 < iters)
+                         mass, wsum, p->V, Vdot, dtDn, dtDc, (const double *)p->ix_sc, p->ix_partial);
+      IMEX_TRY(reduce(nbv, 2));
+      if (it + 1 < iters) {
         hipLaunchKernelGGL(imex_direction_kernel<T>, dim3(nbv), dim3(256), 0, st, (T2 *)p->ix_p, (const T2 *)p->ix_r, mass, wsum, p->V,
                            dtDn, dtDc, (const double *)p->ix_sc);
+        IMEX_TRY(ghosts(p->ix_p));
+      }
     }
     hipLaunchKernelGGL(imex_clamp_kernel<T>, dim3(nbv), dim3(256), 0, st, x, p->V, (T)p->base_n, (T)p->base_c);
     p->cur ^= 1;
   }
+#undef IMEX_TRY
   HIP_TRY(hipGetLastError());
   return FEM_OK;
 }
@@ -494,8 +518,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   if (!ordered || !out || (precision != FEM_PREC_F32 && precision != FEM_PREC_F64) || ksteps < 0 || ksteps > 8)
     return fail(FEM_ERR_INVALID, "fem_plan_create: bad argument");
   if (ksteps > 0 && (!node_parts || n < 1)) return fail(FEM_ERR_INVALID, "fem_plan_create_tiled: partition ranges missing");
-  if ((flags & FEM_PLAN_IMPLICIT) && (ksteps > 0 || shard))
-    return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT needs a sliced-ELL plan of a whole mesh (ksteps = 0, no shard)");
+  if ((flags & FEM_PLAN_IMPLICIT) && ksteps > 0)
+    return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT needs a sliced-ELL plan (ksteps = 0)");
   if ((flags & FEM_PLAN_IMPLICIT) && (flags & FEM_PLAN_DEVICE_ASSEMBLY))
     return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT takes the lumped masses from the host assembly; not combinable with FEM_PLAN_DEVICE_ASSEMBLY");
   fem_model dm;
@@ -829,6 +853,34 @@ int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model
   return p->precision == FEM_PREC_F32 ? runImex<float>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream)
                                       : runImex<double>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream);
   });
+}
+
+int fem_plan_run_imex_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, fem_uint n_own,
+                              const fem_imex_comm *comm, void *stream) {
+  return fem::guarded("fem_plan_run_imex_sharded", [&]() -> int {
+  if (!p || nsteps < 0 || cg_iterations < 1 || cg_iterations > 10000 || !comm || !comm->exchange || !comm->allreduce_sum || n_own > p->V)
+    return fail(FEM_ERR_INVALID, "fem_plan_run_imex_sharded: bad argument");
+  if (!p->can_imex) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_sharded: plan was not created with FEM_PLAN_IMPLICIT");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  return p->precision == FEM_PREC_F32 ? runImex<float>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream, comm, n_own)
+                                      : runImex<double>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream, comm, n_own);
+  });
+}
+
+int fem_plan_pack_vector(fem_plan *p, uint64_t dev_vector, uint64_t dst_dev, void *stream) {
+  if (!p || !dev_vector) return fail(FEM_ERR_INVALID, "fem_plan_pack_vector: bad argument");
+  const fem_uint n = (fem_uint)p->send_idx.n;
+  if (n == 0) return FEM_OK;
+  if (!dst_dev) return fail(FEM_ERR_INVALID, "fem_plan_pack_vector: null destination");
+  if (p->precision == FEM_PREC_F32)
+    hipLaunchKernelGGL(pack_halo_kernel<float2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float2 *)dev_vector,
+                       p->send_idx.p, (float2 *)dst_dev, n);
+  else
+    hipLaunchKernelGGL(pack_halo_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double2 *)dev_vector,
+                       p->send_idx.p, (double2 *)dst_dev, n);
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
 }
 
 int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c) {

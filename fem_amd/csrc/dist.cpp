@@ -77,6 +77,7 @@ struct fem_dist {
   bool sideBusy = false;
   ncclComm_t nccl = nullptr;
   fem_dist_world *world = nullptr;
+  double hostVals[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // in-process all-reduce staging
   int budget = 0;
   bool pending = false, everExchanged = false;
   int nExchanges = 0, nMerged = 0, nSplit = 0;
@@ -89,7 +90,7 @@ size_t pairBytes(const fem_dist *d) { return 2 * (size_t)d->sb; }
 // One all-to-all-v of boundary state from state buffer `which` (0 current, 1 next) into the ghost segments of
 // the neighbours' buffers of the same kind.  Pack on `stream`; everything else on the communication stream,
 // ordered behind the pack by an event; evDone marks the arrival of this rank's ghosts.
-int startExchange(fem_dist *d, int which, hipStream_t stream) {
+int startExchange(fem_dist *d, int which, hipStream_t stream, uint64_t vec = 0) {     // vec != 0: that vector instead of a state buffer
   if (d->world) {
     // the previous exchange's copies out of every send buffer must be done before it is packed again
     d->world->barrier.wait();
@@ -97,12 +98,13 @@ int startExchange(fem_dist *d, int which, hipStream_t stream) {
       for (fem_dist *p : d->world->ranks)
         if (p != d && p->rc[d->rank] > 0) HIP_OK(hipStreamWaitEvent(stream, p->evDone, 0));
   }
-  int rc = fem_plan_pack_halo_from(d->plan, which, (uint64_t)d->sendbuf, stream);
+  int rc = vec ? fem_plan_pack_vector(d->plan, vec, (uint64_t)d->sendbuf, stream)
+               : fem_plan_pack_halo_from(d->plan, which, (uint64_t)d->sendbuf, stream);
   if (rc != FEM_OK) return rc;
   HIP_OK(hipEventRecord(d->evPacked, stream));
   HIP_OK(hipStreamWaitEvent(d->comm, d->evPacked, 0));
-  uint64_t buf = 0;
-  rc = fem_plan_state_buffer(d->plan, which, &buf);
+  uint64_t buf = vec;
+  if (!vec) rc = fem_plan_state_buffer(d->plan, which, &buf);
   if (rc != FEM_OK) return rc;
   char *recv = (char *)buf + (size_t)d->nOwn * pairBytes(d);
   if (d->world) {
@@ -203,9 +205,46 @@ int runPlain(fem_dist *d, int nsteps, double dt, const fem_model *model, hipStre
   return FEM_OK;
 }
 
+// the two communication steps of the distributed conjugate gradients (fem_plan_run_imex_sharded)
+int imexExchange(void *ctx, uint64_t vec, void *stream) {
+  fem_dist *d = (fem_dist *)ctx;
+  FEM_TRY(startExchange(d, 0, (hipStream_t)stream, vec));
+  return waitExchange(d, (hipStream_t)stream);
+}
+
+int imexAllreduce(void *ctx, uint64_t dev, int count, void *stream) {
+  fem_dist *d = (fem_dist *)ctx;
+  hipStream_t st = (hipStream_t)stream;
+  if (!d->world) {
+    NCCL_OK(ncclAllReduce((const void *)dev, (void *)dev, (size_t)count, ncclDouble, ncclSum, d->nccl, st));
+    return FEM_OK;
+  }
+  // in-process world: through the host, summed in rank order on every rank (identical results on all of them)
+  if (count > 8) return fail(FEM_ERR_INVALID, "imexAllreduce: at most 8 values");
+  HIP_OK(hipMemcpyAsync(d->hostVals, (const void *)dev, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+  HIP_OK(hipStreamSynchronize(st));
+  d->world->barrier.wait();
+  double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (fem_dist *p : d->world->ranks)
+    for (int i = 0; i < count; i++) sum[i] += p->hostVals[i];
+  d->world->barrier.wait();                 // nobody overwrites its values before everybody has read them
+  std::memcpy(d->hostVals, sum, sizeof(double) * count);
+  HIP_OK(hipMemcpyAsync((void *)dev, d->hostVals, sizeof(double) * count, hipMemcpyHostToDevice, st));
+  HIP_OK(hipStreamSynchronize(st));
+  return FEM_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int fem_dist_run_imex(fem_dist *d, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream) {
+  if (!d) return fail(FEM_ERR_INVALID, "fem_dist_run_imex: null");
+  fem_imex_comm comm = {d, imexExchange, imexAllreduce};
+  const int rc = fem_plan_run_imex_sharded(d->plan, nsteps, dt, model, cg_iterations, d->nOwn, &comm, stream);
+  if (rc != FEM_OK && g_detail.empty()) g_detail = fem_error_detail();
+  return rc;
+}
 
 int fem_dist_device_count(void) {
   int n = 0;

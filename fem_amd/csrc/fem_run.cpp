@@ -39,6 +39,8 @@ struct Options {
   // --ranks N: the native plan sharded over N ranks (one host thread and, where there are that many, one GPU each),
   // halo exchange over RCCL (or device-to-device copies inside this process: --transport inproc)
   int ranks = 0, krings = 0, precision = FEM_PREC_F32;
+  int imex = 0;                      // --imex ITERS: semi-implicit steps, ITERS CG iterations each (sharded mode)
+  double dtScale = 1.0;              // --dt-scale: time step = scale x 0.1 maxEdgeLen^2
   bool inproc = false;
   std::string dump;                  // raw doubles: n[V] then c[V] of the final state, ordered numbering
 };
@@ -88,7 +90,7 @@ bool initializeData(const fem_mesh *original, int n, const Options &o, const fem
   if (!ok(fem_mesh_stats(r.ordered, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &maxEdge, nullptr, nullptr), "stats")) return false;
   r.nFn.resize(r.V); r.cFn.resize(r.V);
   fem_initial_condition(r.V, o.seed, model.nMax, r.nFn.data(), r.cFn.data());
-  r.dt = 0.1 * maxEdge * maxEdge;
+  r.dt = o.dtScale * 0.1 * maxEdge * maxEdge;
   return true;
 }
 
@@ -267,7 +269,7 @@ class ThreadBarrier {
 double shardedRun(int n, const Options &o, const fem_model &model, const Run &r) {
   const int R = o.ranks;
   if (n < R) { std::fprintf(stderr, "--ranks %d needs at least that many partitions (have %d)\n", R, n); return -1; }
-  const int krings = o.krings > 0 ? o.krings : std::max(2, 2 * o.fuse);
+  const int krings = o.krings > 0 ? o.krings : (o.imex > 0 ? 1 : std::max(2, 2 * o.fuse));
   const int ndev = std::max(1, fem_dist_device_count());
   char uid[128] = {0};
   fem_dist_world *world = nullptr;
@@ -281,7 +283,7 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
   std::vector<fem_uint> ghosts(R, 0);
   int errorsRound2 = 0;
   std::vector<double> hn, hc;
-  const bool check = r.V <= 4000000;      // CPUrun of a large mesh takes minutes: check up to 4M vertices
+  const bool check = r.V <= 4000000 && o.imex == 0;   // CPUrun (explicit steps) of a large mesh takes minutes: check up to 4M vertices
   if (check && !hostRun(r, model, 2, hn, hc)) return -1;
 
   auto body = [&](int rank) {
@@ -297,8 +299,9 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
     do {
       if (fem_dist_set_device(rank % ndev) != FEM_OK) { bail("device", true); break; }
       if (fem_shard_create(r.ordered, n, r.nodeParts.data(), rank, R, krings, &shard) != FEM_OK) { bail("shard", false); break; }
-      const int rc = o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), shard, o.precision, &model, o.fuse, &plan)
-                                : fem_plan_create_shard(r.ordered, shard, o.precision, &model, &plan);
+      const int rc = o.imex > 0 ? fem_plan_create_ex(r.ordered, 0, nullptr, shard, o.precision, &model, 0, FEM_PLAN_IMPLICIT, &plan)
+                     : (o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), shard, o.precision, &model, o.fuse, &plan)
+                                   : fem_plan_create_shard(r.ordered, shard, o.precision, &model, &plan));
       if (rc != FEM_OK) { bail("plan", false); break; }
       fem_uint ownB = 0, ownE = 0, nLocal = 0, nSend = 0;
       fem_shard_info(shard, &ownB, &ownE, &nLocal, &nSend);
@@ -325,7 +328,7 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
     };
     if (up) {
       // two warm-up steps and the check against CPUrun (main.cpp:480-541)
-      if (fem_dist_run(dist, 2, r.dt, &model, stream) != FEM_OK) { bail("step", true); }
+      if ((o.imex > 0 ? fem_dist_run_imex(dist, 2, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2, r.dt, &model, stream)) != FEM_OK) { bail("step", true); }
       else download();
     }
     bar.wait();
@@ -333,7 +336,8 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
     bar.wait();
     if (up && !failed && !o.debug) {
       const double t0 = seconds();
-      if (fem_dist_run(dist, 2 * o.maxIt, r.dt, &model, stream) != FEM_OK || fem_dist_wait(dist, stream) != FEM_OK ||
+      if ((o.imex > 0 ? fem_dist_run_imex(dist, 2 * o.maxIt, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2 * o.maxIt, r.dt, &model, stream)) != FEM_OK ||
+          fem_dist_wait(dist, stream) != FEM_OK ||
           fem_dist_stream_synchronize(stream) != FEM_OK)
         bail("step", true);
       rankMs[rank] = (seconds() - t0) * 1e3;
@@ -389,7 +393,9 @@ int usage() {
                "  --ranks N        native plan sharded over N ranks (threads; GPU = rank mod device count), halo exchange over\n"
                "                   RCCL every --rings K steps (default 2 x fuse); --transport inproc: device-to-device copies\n"
                "                   inside this process instead (all ranks may share one GPU); --f64: fp64 plans;\n"
-               "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering)\n");
+               "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering);\n"
+               "                   --imex ITERS: semi-implicit steps (diffusion by ITERS CG iterations, dot products all-reduced\n"
+               "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2\n");
   return 2;
 }
 
@@ -407,7 +413,7 @@ int main(int argc, char **argv) {
     else if (a == "--host-constants") o.hostConstants = true;
     else if (a == "--f64") o.precision = FEM_PREC_F64;
     else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out" ||
-             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump") {
+             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--dt-scale") {
       const char *v = value();
       if (!v) return usage();
       if (a == "-n") {
@@ -422,13 +428,16 @@ int main(int argc, char **argv) {
       else if (a == "--rings") o.krings = std::atoi(v);
       else if (a == "--transport") { if (!std::strcmp(v, "inproc")) o.inproc = true; else if (std::strcmp(v, "rccl")) return usage(); }
       else if (a == "--dump") o.dump = v;
+      else if (a == "--imex") o.imex = std::atoi(v);
+      else if (a == "--dt-scale") o.dtScale = std::atof(v);
       else o.out = v;
     } else if (!a.empty() && a[0] == '-') return usage();
     else if (o.file.empty()) o.file = a;
     else return usage();
   }
   if (o.file.empty() || o.startN < 1 || o.endN < o.startN || o.maxIt < 1 || o.fuse < 0 || o.fuse > 8 || o.rowsPerPart < 1 ||
-      (o.hostConstants && !o.native) || o.ranks < 0 || o.ranks > 64 || o.krings < 0)
+      (o.hostConstants && !o.native) || o.ranks < 0 || o.ranks > 64 || o.krings < 0 || o.imex < 0 || (o.imex > 0 && o.ranks < 1) ||
+      !(o.dtScale > 0))
     return usage();
 
   fem_model model;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void imex_apply_kernel(const typename Vec<T>::
                                                          typename Vec<T>::t2 *__restrict__ r, typename Vec<T>::t2 *__restrict__ pout,
                                                          const uint *__restrict__ slice_off, const uint *__restrict__ idx,
                                                          const T *__restrict__ wgt, const T *__restrict__ mass,
-                                                         const T *__restrict__ wsum, uint V, uint nslices, uint nblocks, T dtDn, T dtDc,
+                                                         const T *__restrict__ wsum, uint V, uint Vdot, uint nslices, uint nblocks, T dtDn, T dtDc,
                                                          int mode, double *__restrict__ partial) {
   typedef typename Vec<T>::t2 T2;
   const uint b = blockIdx.x, q8 = nblocks >> 3, r8 = nblocks & 7u, xcd = b & 7u;
@@ -52,14 +52,14 @@ __global__ __launch_bounds__(256) void imex_apply_kernel(const typename Vec<T>::
         T2 o;
         o.x = a * (s.x - dtDn * ln); o.y = a * (s.y - dtDc * lc);
         q[v] = o;
-        d0 = (double)s.x * (double)o.x; d1 = (double)s.y * (double)o.y;
+        if (v < Vdot) { d0 = (double)s.x * (double)o.x; d1 = (double)s.y * (double)o.y; }   // a shard sums its owned rows only
       } else {
         const T ws = wsum[v];
         T2 rr, pp;
         rr.x = a * dtDn * ln; rr.y = a * dtDc * lc;                 // M b - A b
         pp.x = rr.x / (a * (1 + dtDn * ws)); pp.y = rr.y / (a * (1 + dtDc * ws));
         r[v] = rr; pout[v] = pp;
-        d0 = (double)rr.x * (double)pp.x; d1 = (double)rr.y * (double)pp.y;
+        if (v < Vdot) { d0 = (double)rr.x * (double)pp.x; d1 = (double)rr.y * (double)pp.y; }
       }
     }
   }
@@ -101,11 +101,32 @@ __global__ __launch_bounds__(256) void imex_scalar_kernel(const double *__restri
   }
 }
 
+// The same in two halves for a sharded solve: the local sums (this rank's owned rows) go to loc[0..1], are summed over
+// the ranks by the caller's all-reduce, and imex_finish_kernel forms alpha / beta from the global sums on every rank.
+__global__ __launch_bounds__(256) void imex_reduce_kernel(const double *__restrict__ partial, uint n, double *__restrict__ loc) {
+  __shared__ double sp[8];
+  double d0 = 0, d1 = 0;
+  for (uint i = threadIdx.x; i < n; i += 256) { d0 += partial[2 * (size_t)i]; d1 += partial[2 * (size_t)i + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+  if ((threadIdx.x & 63) == 0) { sp[2 * (threadIdx.x >> 6)] = d0; sp[2 * (threadIdx.x >> 6) + 1] = d1; }
+  __syncthreads();
+  if (threadIdx.x == 0) { loc[0] = (sp[0] + sp[2]) + (sp[4] + sp[6]); loc[1] = (sp[1] + sp[3]) + (sp[5] + sp[7]); }
+}
+
+__global__ void imex_finish_kernel(const double *__restrict__ loc, double *__restrict__ sc, int what) {
+  if (threadIdx.x != 0) return;
+  const double s0 = loc[0], s1 = loc[1];
+  if (what == 0) { sc[0] = s0; sc[1] = s1; sc[6] = s0; sc[7] = s1; sc[8] = s0; sc[9] = s1; }
+  else if (what == 1) { sc[2] = s0 > 0 ? sc[0] / s0 : 0.0; sc[3] = s1 > 0 ? sc[1] / s1 : 0.0; }
+  else { sc[4] = sc[0] > 0 ? s0 / sc[0] : 0.0; sc[5] = sc[1] > 0 ? s1 / sc[1] : 0.0; sc[0] = s0; sc[1] = s1; sc[8] = s0; sc[9] = s1; }
+}
+
 // x += alpha p;  r -= alpha q;  partials of r.(r/diag)
 template <typename T>
 __global__ __launch_bounds__(256) void imex_update_kernel(typename Vec<T>::t2 *__restrict__ x, typename Vec<T>::t2 *__restrict__ r,
                                                           const typename Vec<T>::t2 *__restrict__ p, const typename Vec<T>::t2 *__restrict__ q,
-                                                          const T *__restrict__ mass, const T *__restrict__ wsum, uint V, T dtDn, T dtDc,
+                                                          const T *__restrict__ mass, const T *__restrict__ wsum, uint V, uint Vdot, T dtDn, T dtDc,
                                                           const double *__restrict__ sc, double *__restrict__ partial) {
   typedef typename Vec<T>::t2 T2;
   const uint v = blockIdx.x * 256 + threadIdx.x;
@@ -118,8 +139,10 @@ __global__ __launch_bounds__(256) void imex_update_kernel(typename Vec<T>::t2 *_
     rv.x -= a0 * qv.x; rv.y -= a1 * qv.y;
     x[v] = xv; r[v] = rv;
     const T a = mass[v], ws = wsum[v];
-    d0 = (double)rv.x * (double)(rv.x / (a * (1 + dtDn * ws)));
-    d1 = (double)rv.y * (double)(rv.y / (a * (1 + dtDc * ws)));
+    if (v < Vdot) {
+      d0 = (double)rv.x * (double)(rv.x / (a * (1 + dtDn * ws)));
+      d1 = (double)rv.y * (double)(rv.y / (a * (1 + dtDc * ws)));
+    }
   }
   __shared__ double sp[8];
 #pragma unroll

@@ -53,6 +53,11 @@ void fem_dist_destroy(fem_dist *d);
 /* nsteps time steps, exchanging when the ghost rings are used up; asynchronous on `stream` (compute) and on the
  * rank's own communication stream.  The timed loop of main.cpp:558-562 for a shard. */
 int fem_dist_run(fem_dist *d, int nsteps, double dt, const fem_model *model, void *stream);
+/* Semi-implicit (IMEX) steps on the shard: fem_plan_run_imex_sharded (fem_hip.h) with the ghost exchange of the
+ * right-hand side and of every search direction as grouped ncclSend / ncclRecv, and the two dot products of a CG
+ * iteration as ncclAllReduce of two doubles, all stream-ordered on `stream` (no host synchronisation with RCCL).
+ * The plan must be a sliced-ELL plan of the shard created with FEM_PLAN_IMPLICIT; one ghost ring is enough. */
+int fem_dist_run_imex(fem_dist *d, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
 /* makes `stream` wait for an exchange still in flight (call before reading the state back) */
 int fem_dist_wait(fem_dist *d, void *stream);
 /* counters since creation: exchanges started, groups run as one launch / interior-first */

@@ -262,7 +262,7 @@ int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_p
  * be re-assembled there (fem_plan_assemble) -- initMeshStats on the GPU, mesh_function.cpp:27-67.
  * ksteps = 0: sliced-ELL layout; n/node_parts may then be 0/NULL. */
 #define FEM_PLAN_DEVICE_ASSEMBLY 1u
-#define FEM_PLAN_IMPLICIT 2u          /* sliced-ELL plan of a whole mesh: enables fem_plan_run_imex (not with DEVICE_ASSEMBLY) */
+#define FEM_PLAN_IMPLICIT 2u          /* sliced-ELL plan (whole mesh or a shard): enables fem_plan_run_imex[_sharded] (not with DEVICE_ASSEMBLY) */
 int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                        const fem_shard *shard, int precision, const fem_model *model, int ksteps,
                        unsigned flags, fem_plan **out);
@@ -338,6 +338,24 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
  * preconditioned residual norm of the last solve relative to its first one (synchronises). */
 int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
 int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c);
+/* The same steps on a shard's plan (fem_plan_create_ex(..., shard, ..., ksteps = 0, FEM_PLAN_IMPLICIT); one ghost ring is
+ * enough): the conjugate-gradient iteration distributed over the ranks.  The library runs the kernels; the caller
+ * supplies the two communication steps as callbacks, both asynchronous on `stream`:
+ *   exchange(ctx, dev_vector, stream): fill the ghost rows [n_own, n_local) of a device vector of n_local interleaved
+ *     pairs of the plan's scalar type from their owners (fem_plan_pack_vector gathers this rank's send rows);
+ *   allreduce_sum(ctx, dev_doubles, count, stream): sum `count` doubles in device memory over all ranks, in place.
+ * Per time step: one exchange of the right-hand side, then per CG iteration one exchange of the search direction and two
+ * all-reduces of two doubles (p.q and r.z, owned rows only) -- the one place on this path where an all-reduce appears
+ * (SURVEY.md 8f-4).  libfem_dist.so (fem_dist_run_imex) supplies both over RCCL. */
+typedef struct {
+  void *ctx;
+  int (*exchange)(void *ctx, uint64_t dev_vector, void *stream);
+  int (*allreduce_sum)(void *ctx, uint64_t dev_doubles, int count, void *stream);
+} fem_imex_comm;
+int fem_plan_run_imex_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, fem_uint n_own,
+                              const fem_imex_comm *comm, void *stream);
+/* gathers this rank's send rows of ANY device vector of n_local pairs (fem_plan_pack_halo does it for the state) */
+int fem_plan_pack_vector(fem_plan *p, uint64_t dev_vector, uint64_t dst_dev, void *stream);
 /* device pointer of the current state buffer (interleaved (n - base_n,
  * c - base_c) pairs of the plan's scalar type), its vertex count, bytes per
  * scalar and the two base values */

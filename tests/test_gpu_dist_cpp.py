@@ -85,3 +85,31 @@ def test_python_driver_agrees_with_cpp_host(sphere_off, reference, tmp_path):
                  fuse=4, pg="nccl")[0]
     # (the Python worker builds the sphere in memory, fem_run reads its rounded .off text: 1e-9 apart, not bit-equal)
     assert rel_l2(res["n"], n_cpp) <= 1e-7 and rel_l2(res["c"], c_cpp) <= 1e-7
+
+
+@pytest.mark.parametrize("ranks,transport", [(1, "rccl"), (2, "inproc"), (4, "inproc")])
+def test_sharded_semi_implicit_steps(sphere_off, tmp_path, ranks, transport):
+    """semi-implicit stepping on shards (fem_dist_run_imex): conjugate gradients distributed over the ranks -- one ghost
+    ring, an exchange of the right-hand side and of every search direction, the dot products over owned rows summed by
+    an all-reduce (ncclAllReduce at world size 1 here; through the host between the in-process ranks) -- against the
+    single-GPU solver (fem_plan_run_imex, itself checked against a scipy direct solve in test_gpu_implicit.py)"""
+    iters, scale, cg = 3, 6.0, 30
+    dump = str(tmp_path / "imex.bin")
+    cmd = [FEM_RUN, sphere_off, "--ranks", str(ranks), "-n", str(NPARTS), "--iterations", str(iters), "--seed", "3", "--transport", transport,
+           "--imex", str(cg), "--dt-scale", str(scale), "--f64", "--dump", dump]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
+    assert res.returncode == 0 and "Best time" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
+    raw = np.fromfile(dump)
+    V = len(raw) // 2
+    pts, tri, _ = fa.off_read(sphere_off)
+    part = fa.Mesh(pts, tri).partition(NPARTS)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = scale * 0.1 * om.stats()["maxEdgeLen"] ** 2
+    plan = fa.Plan(om, fa.PREC_F64, implicit=True)
+    n0, c0 = fa.initial_condition(om.V, 3)
+    plan.set_state(n0, c0)
+    plan.run_imex(2 + 2 * iters, dt, fa.default_model(), cg)
+    n_ref, c_ref = plan.get_state()
+    assert V == om.V and not np.array_equal(n_ref, n0)
+    assert rel_l2(raw[:V], n_ref) <= 1e-10 and rel_l2(raw[V:], c_ref) <= 1e-10
