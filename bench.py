@@ -162,11 +162,12 @@ def verify_against_oracle(runner, state, total_steps, seed=1):
     dev = max(float(np.linalg.norm(n_ref - runner.model.nMax)), 1e-300)
     return {"rel_l2_n": rel(n, n_ref), "rel_l2_c": rel(c, c_ref), "rel_l2_n_deviation": float(np.linalg.norm(n - n_ref) / dev),
             "max_abs_n": float(np.abs(n - n_ref).max()), "steps": total_steps, "tolerance": 1e-5 if runner.precision == "f32" else 1e-11,
-            "state_changed": bool(np.abs(n_ref - n0).max() > 0),
+            "state_changed": bool(np.abs(n - n0).max() > 0),      # the device state left the initial condition: the kernel ran
             "oracle": "fo_step_f64 (oracle/, %d threads), same IC and ordered mesh, %.1f s" % (threads, time.perf_counter() - t0)}
 
 
 def main():
+    verify_failed = False
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -367,10 +368,14 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_deform() if deform else cpu_baseline()
         if final_state is not None:
-            out["verify"] = (verify_deform if deform else verify_against_oracle)(runner, final_state, args.warmup + args.steps)
+            v = out["verify"] = (verify_deform if deform else verify_against_oracle)(runner, final_state, args.warmup + args.steps)
+            v["ok"] = bool(max(v["rel_l2_n"], v["rel_l2_c"]) <= v["tolerance"] and v.get("state_changed", True))
+            verify_failed = not v["ok"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    if verify_failed:
+        raise SystemExit("bench.py: the timed run's result differs from the oracle beyond the tolerance (see \"verify\")")
 
 
 if __name__ == "__main__":
