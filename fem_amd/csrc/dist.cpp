@@ -12,11 +12,15 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fem_dist.h"
@@ -39,20 +43,52 @@ int fail(int status, const std::string &what) {
     if (r_ != ncclSuccess) return fail(FEM_ERR_DEVICE, std::string(#call ": ") + ncclGetErrorString(r_)); \
   } while (0)
 
-class Barrier {                         // reusable, for the threads of an in-process world
+#define FEM_TRY(call)            \
+  do {                           \
+    const int rc_ = (call);      \
+    if (rc_ != FEM_OK) return rc_; \
+  } while (0)
+
+// Reusable barrier for the threads of an in-process world.  A rank that leaves its loop with an error breaks the
+// barrier (abort()), and a rank that waits longer than the limit (FEM_DIST_BARRIER_SECONDS, default 60) breaks it
+// too: the others then return an error instead of waiting for a rank that will not come.
+class Barrier {
  public:
-  explicit Barrier(int n) : n_(n) {}
-  void wait() {
+  explicit Barrier(int n) : n_(n) {
+    const char *e = getenv("FEM_DIST_BARRIER_SECONDS");
+    if (e && atof(e) > 0) limit_ = atof(e);
+  }
+  bool wait() {                          // false: broken
     std::unique_lock<std::mutex> lock(m_);
+    if (broken_) return false;
     const int gen = gen_;
-    if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); }
-    else cv_.wait(lock, [&] { return gen != gen_; });
+    if (++count_ == n_) { count_ = 0; gen_++; cv_.notify_all(); return true; }
+    const bool ok = cv_.wait_for(lock, std::chrono::duration<double>(limit_), [&] { return gen != gen_ || broken_; });
+    if (!ok) { broken_ = true; cv_.notify_all(); }
+    return !broken_;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lock(m_);
+    broken_ = true;
+    cv_.notify_all();
   }
  private:
   std::mutex m_;
   std::condition_variable cv_;
   int n_, count_ = 0, gen_ = 0;
+  bool broken_ = false;
+  double limit_ = 60.0;
 };
+
+const bool g_trace = getenv("FEM_DIST_TRACE") && strcmp(getenv("FEM_DIST_TRACE"), "0") != 0;   // one stderr line per stage
+#define TRACE(d, ...)                                              \
+  do {                                                             \
+    if (g_trace) {                                                 \
+      char b_[160];                                                \
+      std::snprintf(b_, sizeof b_, __VA_ARGS__);                   \
+      std::fprintf(stderr, "[fem_dist %d] %s\n", (d)->rank, b_);   \
+    }                                                              \
+  } while (0)
 
 }  // namespace
 
@@ -90,11 +126,53 @@ size_t pairBytes(const fem_dist *d) { return 2 * (size_t)d->sb; }
 // One all-to-all-v of boundary state from state buffer `which` (0 current, 1 next) into the ghost segments of
 // the neighbours' buffers of the same kind.  Pack on `stream`; everything else on the communication stream,
 // ordered behind the pack by an event; evDone marks the arrival of this rank's ghosts.
+// Host-side wait for an event / a stream by polling (hipEventQuery / hipStreamQuery) with a limit, so that work
+// that never completes becomes an error message instead of a thread asleep in the runtime (FEM_DIST_WAIT=block:
+// hipEventSynchronize / hipStreamSynchronize instead).
+const bool g_blockingWait = getenv("FEM_DIST_WAIT") && !strcmp(getenv("FEM_DIST_WAIT"), "block");
+double waitLimitSeconds() {
+  const char *e = getenv("FEM_DIST_BARRIER_SECONDS");
+  return e && atof(e) > 0 ? atof(e) : 60.0;
+}
+template <typename Query> int pollUntilDone(Query query, const char *what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  const double limit = waitLimitSeconds();
+  for (unsigned spins = 0;; spins++) {
+    const hipError_t e = query();
+    if (e == hipSuccess) return FEM_OK;
+    if (e != hipErrorNotReady) return fail(FEM_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    if (spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    else std::this_thread::yield();
+    if ((spins & 255) == 255 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+      return fail(FEM_ERR_DEVICE, std::string(what) + ": not complete after " + std::to_string((int)limit) + " s");
+  }
+}
+int hostWaitEvent(hipEvent_t ev, const char *what) {
+  if (g_blockingWait) { HIP_OK(hipEventSynchronize(ev)); return FEM_OK; }
+  return pollUntilDone([&] { return hipEventQuery(ev); }, what);
+}
+
+int brokenBarrier(const fem_dist *d, const char *where) {
+  return fail(FEM_ERR_DEVICE, std::string("in-process world: barrier broken at ") + where + " of rank " + std::to_string(d->rank) +
+                                  " (another rank failed, or did not arrive within the limit)");
+}
+
+// In-process worlds order the ranks' copies on the device (default: streams wait for the other ranks' events, the
+// host only meets at barriers so that every event is recorded before it is waited for) or on the host
+// (FEM_DIST_INPROC=host: a rank waits for its own events and the ranks meet at a barrier, so no stream ever waits for
+// an event that another thread recorded -- a diagnostic).
+const bool g_inprocEvents = !(getenv("FEM_DIST_INPROC") && !strcmp(getenv("FEM_DIST_INPROC"), "host"));
+
 int startExchange(fem_dist *d, int which, hipStream_t stream, uint64_t vec = 0) {     // vec != 0: that vector instead of a state buffer
+  TRACE(d, "exchange %d: begin", d->nExchanges);
   if (d->world) {
     // the previous exchange's copies out of every send buffer must be done before it is packed again
-    d->world->barrier.wait();
-    if (d->everExchanged)
+    if (!g_inprocEvents && d->everExchanged) {
+      TRACE(d, "exchange %d: waiting for the copies of the previous one", d->nExchanges);
+      FEM_TRY(hostWaitEvent(d->evDone, "the copies of the previous exchange"));     // this rank's copies out of the others' buffers
+    }
+    if (!d->world->barrier.wait()) return brokenBarrier(d, "the start of an exchange");
+    if (g_inprocEvents && d->everExchanged)
       for (fem_dist *p : d->world->ranks)
         if (p != d && p->rc[d->rank] > 0) HIP_OK(hipStreamWaitEvent(stream, p->evDone, 0));
   }
@@ -108,13 +186,18 @@ int startExchange(fem_dist *d, int which, hipStream_t stream, uint64_t vec = 0) 
   if (rc != FEM_OK) return rc;
   char *recv = (char *)buf + (size_t)d->nOwn * pairBytes(d);
   if (d->world) {
-    d->world->barrier.wait();            // every rank has recorded its pack event
+    if (!g_inprocEvents) {
+      TRACE(d, "exchange %d: waiting for the pack", d->nExchanges);
+      FEM_TRY(hostWaitEvent(d->evPacked, "the pack of an exchange"));     // this rank's send buffer is filled
+    }
+    TRACE(d, "exchange %d: packed", d->nExchanges);
+    if (!d->world->barrier.wait()) return brokenBarrier(d, "the pack of an exchange");   // every rank has packed (events: recorded its pack event)
     for (int r = 0; r < d->nranks; r++) {
       if (r == d->rank || d->rc[r] == 0) continue;
       fem_dist *p = d->world->ranks[r];
-      HIP_OK(hipStreamWaitEvent(d->comm, p->evPacked, 0));
+      if (g_inprocEvents) HIP_OK(hipStreamWaitEvent(d->comm, p->evPacked, 0));
       HIP_OK(hipMemcpyAsync(recv + d->roff[r] * pairBytes(d), (const char *)p->sendbuf + p->soff[d->rank] * pairBytes(d),
-                            (size_t)d->rc[r] * pairBytes(d), hipMemcpyDefault, d->comm));
+                            (size_t)d->rc[r] * pairBytes(d), hipMemcpyDeviceToDevice, d->comm));
     }
   } else {
     const ncclDataType_t ty = d->sb == 4 ? ncclFloat32 : ncclFloat64;
@@ -128,6 +211,7 @@ int startExchange(fem_dist *d, int which, hipStream_t stream, uint64_t vec = 0) 
     NCCL_OK(ncclGroupEnd());
   }
   HIP_OK(hipEventRecord(d->evDone, d->comm));
+  TRACE(d, "exchange %d: issued", d->nExchanges);
   d->pending = true;
   d->everExchanged = true;
   d->nExchanges++;
@@ -139,12 +223,6 @@ int waitExchange(fem_dist *d, hipStream_t stream) {
   d->pending = false;
   return FEM_OK;
 }
-
-#define FEM_TRY(call)            \
-  do {                           \
-    const int rc_ = (call);      \
-    if (rc_ != FEM_OK) return rc_; \
-  } while (0)
 
 int runOverlapped(fem_dist *d, int nsteps, double dt, const fem_model *model, hipStream_t stream) {
   const fem_uint nI = d->nI, nB = d->nB, nG = d->nG;
@@ -223,11 +301,11 @@ int imexAllreduce(void *ctx, uint64_t dev, int count, void *stream) {
   if (count > 8) return fail(FEM_ERR_INVALID, "imexAllreduce: at most 8 values");
   HIP_OK(hipMemcpyAsync(d->hostVals, (const void *)dev, sizeof(double) * count, hipMemcpyDeviceToHost, st));
   HIP_OK(hipStreamSynchronize(st));
-  d->world->barrier.wait();
+  if (!d->world->barrier.wait()) return brokenBarrier(d, "an all-reduce");
   double sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (fem_dist *p : d->world->ranks)
     for (int i = 0; i < count; i++) sum[i] += p->hostVals[i];
-  d->world->barrier.wait();                 // nobody overwrites its values before everybody has read them
+  if (!d->world->barrier.wait()) return brokenBarrier(d, "an all-reduce");   // nobody overwrites its values before everybody has read them
   std::memcpy(d->hostVals, sum, sizeof(double) * count);
   HIP_OK(hipMemcpyAsync((void *)dev, d->hostVals, sizeof(double) * count, hipMemcpyHostToDevice, st));
   HIP_OK(hipStreamSynchronize(st));
@@ -240,9 +318,11 @@ extern "C" {
 
 int fem_dist_run_imex(fem_dist *d, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream) {
   if (!d) return fail(FEM_ERR_INVALID, "fem_dist_run_imex: null");
+  g_detail.clear();
   fem_imex_comm comm = {d, imexExchange, imexAllreduce};
   const int rc = fem_plan_run_imex_sharded(d->plan, nsteps, dt, model, cg_iterations, d->nOwn, &comm, stream);
   if (rc != FEM_OK && g_detail.empty()) g_detail = fem_error_detail();
+  if (rc != FEM_OK && d->world) d->world->barrier.abort();     // the other ranks must not wait for this one
   return rc;
 }
 
@@ -269,8 +349,8 @@ void fem_dist_stream_destroy(void *stream) {
 }
 
 int fem_dist_stream_synchronize(void *stream) {
-  HIP_OK(hipStreamSynchronize((hipStream_t)stream));
-  return FEM_OK;
+  if (g_blockingWait) { HIP_OK(hipStreamSynchronize((hipStream_t)stream)); return FEM_OK; }
+  return pollUntilDone([&] { return hipStreamQuery((hipStream_t)stream); }, "fem_dist_stream_synchronize");
 }
 
 int fem_dist_rccl_unique_id(char id_out[128]) {
@@ -363,6 +443,8 @@ int fem_dist_create(fem_plan *plan, const fem_shard *shard, void *comm, fem_dist
   if (ks > 0 && d->mode != 0) {
     if (fem_plan_tile_classes(plan, &d->nI, &d->nB, &d->nG) == FEM_OK) d->classes = true;
   }
+  static std::mutex setupMutex;            // ranks of an in-process world create their streams one after the other
+  std::lock_guard<std::mutex> setupLock(setupMutex);
   hipError_t e = hipStreamCreateWithFlags(&d->comm, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evPacked, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming);
@@ -370,7 +452,13 @@ int fem_dist_create(fem_plan *plan, const fem_shard *shard, void *comm, fem_dist
   if (e == hipSuccess && d->classes && !(bsEnv && !strcmp(bsEnv, "0"))) {
     int lo = 0, hi = 0;
     e = hipDeviceGetStreamPriorityRange(&lo, &hi);        // hi = the numerically lowest value = greatest priority
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, hi);
+    // Normal priority unless FEM_SIDE_PRIORITY=high.  A high-priority side stream starts the boundary tiles a little
+    // earlier (8-GPU rehearsal 6.25x instead of 6.22x), but on this ROCm 7.2 / MI355X pool several host threads of one
+    // process, each with a high-priority stream that waits for events of normal-priority streams, stalled for seconds
+    // and now and then for good (tools/inproc_hang_probe.sh: 1 run in ~17 never finished; 0 of 240 at normal priority).
+    const char *pr = getenv("FEM_SIDE_PRIORITY");
+    const int prio = pr && !strcmp(pr, "high") ? hi : 0;
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, prio);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evTop, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evSide, hipEventDisableTiming);
   }
@@ -388,7 +476,13 @@ const char *fem_dist_error_detail(void) { return g_detail.c_str(); }
 
 int fem_dist_run(fem_dist *d, int nsteps, double dt, const fem_model *model, void *stream) {
   if (!d || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_dist_run: bad argument");
-  return d->classes ? runOverlapped(d, nsteps, dt, model, (hipStream_t)stream) : runPlain(d, nsteps, dt, model, (hipStream_t)stream);
+  g_detail.clear();
+  TRACE(d, "run %d steps (budget %d)", nsteps, d->budget);
+  const int rc = d->classes ? runOverlapped(d, nsteps, dt, model, (hipStream_t)stream) : runPlain(d, nsteps, dt, model, (hipStream_t)stream);
+  if (rc != FEM_OK && g_detail.empty()) g_detail = fem_error_detail();
+  if (rc != FEM_OK && d->world) d->world->barrier.abort();     // the other ranks must not wait for this one
+  TRACE(d, "run: queued, status %d", rc);
+  return rc;
 }
 
 int fem_dist_wait(fem_dist *d, void *stream) {

@@ -41,6 +41,7 @@ struct Options {
   int ranks = 0, krings = 0, precision = FEM_PREC_F32;
   int imex = 0;                      // --imex ITERS: semi-implicit steps, ITERS CG iterations each (sharded mode)
   double dtScale = 1.0;              // --dt-scale: time step = scale x 0.1 maxEdgeLen^2
+  double watchdog = 0;               // --watchdog SECONDS: a sharded run that has not finished by then reports where every rank is and exits 124
   bool inproc = false;
   std::string dump;                  // raw doubles: n[V] then c[V] of the final state, ordered numbering
 };
@@ -286,6 +287,23 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
   const bool check = r.V <= 4000000 && o.imex == 0;   // CPUrun (explicit steps) of a large mesh takes minutes: check up to 4M vertices
   if (check && !hostRun(r, model, 2, hn, hc)) return -1;
 
+  // where every rank is, for the watchdog: a run that hangs (a rank waiting for the GPU or for another rank) ends with
+  // a message instead of at the caller's time limit
+  std::vector<std::atomic<const char *>> stage(R);
+  for (auto &s : stage) s = "start";
+  std::mutex wdMutex;
+  std::condition_variable wdCv;
+  bool wdDone = false;
+  std::thread watchdog;
+  if (o.watchdog > 0)
+    watchdog = std::thread([&]() {
+      std::unique_lock<std::mutex> lock(wdMutex);
+      if (wdCv.wait_for(lock, std::chrono::duration<double>(o.watchdog), [&] { return wdDone; })) return;
+      for (int i = 0; i < R; i++) std::fprintf(stderr, "watchdog: rank %d is at: %s\n", i, stage[i].load());
+      std::fflush(stderr);
+      std::_Exit(124);
+    });
+
   auto body = [&](int rank) {
     fem_shard *shard = nullptr;
     fem_plan *plan = nullptr;
@@ -297,8 +315,11 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
     };
     bool up = false;
     do {
+      stage[rank] = "set-up: device";
       if (fem_dist_set_device(rank % ndev) != FEM_OK) { bail("device", true); break; }
+      stage[rank] = "set-up: shard";
       if (fem_shard_create(r.ordered, n, r.nodeParts.data(), rank, R, krings, &shard) != FEM_OK) { bail("shard", false); break; }
+      stage[rank] = "set-up: plan";
       const int rc = o.imex > 0 ? fem_plan_create_ex(r.ordered, 0, nullptr, shard, o.precision, &model, 0, FEM_PLAN_IMPLICIT, &plan)
                      : (o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), shard, o.precision, &model, o.fuse, &plan)
                                    : fem_plan_create_shard(r.ordered, shard, o.precision, &model, &plan));
@@ -310,50 +331,65 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
       fem_shard_arrays(shard, &l2g, nullptr, nullptr, nullptr);
       std::vector<double> ln(nLocal), lc(nLocal);
       for (fem_uint i = 0; i < nLocal; i++) { ln[i] = r.nFn[l2g[i]]; lc[i] = r.cFn[l2g[i]]; }
+      stage[rank] = "set-up: upload";
       if (fem_plan_set_state(plan, ln.data(), lc.data()) != FEM_OK) { bail("upload", false); break; }
+      stage[rank] = "set-up: streams and communicator";
       if (fem_dist_stream_create(&stream) != FEM_OK) { bail("stream", true); break; }
       if (!o.inproc && fem_dist_rccl_comm_create(uid, rank, R, &comm) != FEM_OK) { bail("RCCL communicator", true); break; }
       if (fem_dist_create(plan, shard, comm, world, &dist) != FEM_OK) { bail("fem_dist_create", true); break; }
       up = true;
     } while (false);
+    stage[rank] = "set-up done, waiting for the other ranks";
     bar.wait();                                        // every rank is set up (or has failed)
     if (failed) up = false;
     auto download = [&]() {
       fem_uint ownB = 0, ownE = 0, nLocal = 0;
       fem_shard_info(shard, &ownB, &ownE, &nLocal, nullptr);
       std::vector<double> ln(nLocal), lc(nLocal);
+      stage[rank] = "download (device synchronize)";
       if (fem_dist_wait(dist, stream) != FEM_OK || fem_plan_get_state(plan, ln.data(), lc.data()) != FEM_OK) { failed = 1; return; }
       std::copy(ln.begin(), ln.begin() + (ownE - ownB), gn.begin() + ownB);
       std::copy(lc.begin(), lc.begin() + (ownE - ownB), gc.begin() + ownB);
     };
     if (up) {
       // two warm-up steps and the check against CPUrun (main.cpp:480-541)
+      stage[rank] = "two warm-up steps (issuing)";
       if ((o.imex > 0 ? fem_dist_run_imex(dist, 2, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2, r.dt, &model, stream)) != FEM_OK) { bail("step", true); }
       else download();
     }
+    stage[rank] = "warm-up done, waiting for the other ranks";
     bar.wait();
     if (rank == 0 && !failed && check) errorsRound2 = reportRound(2, gn, gc, hn, hc, o.verbose || o.debug);
     bar.wait();
     if (up && !failed && !o.debug) {
       const double t0 = seconds();
+      stage[rank] = "timed steps (issuing)";
       if ((o.imex > 0 ? fem_dist_run_imex(dist, 2 * o.maxIt, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2 * o.maxIt, r.dt, &model, stream)) != FEM_OK ||
           fem_dist_wait(dist, stream) != FEM_OK ||
-          fem_dist_stream_synchronize(stream) != FEM_OK)
+          (stage[rank] = "timed steps (stream synchronize)", fem_dist_stream_synchronize(stream)) != FEM_OK)
         bail("step", true);
       rankMs[rank] = (seconds() - t0) * 1e3;
       fem_dist_stats(dist, &exchanges[rank], &mergedG[rank], &splitG[rank]);
       if (!failed && (!o.dump.empty() || !o.out.empty())) download();
     }
+    stage[rank] = "timed steps done, waiting for the other ranks";
     bar.wait();
+    stage[rank] = "teardown";
     fem_dist_destroy(dist);
     fem_dist_rccl_comm_destroy(comm);
     fem_dist_stream_destroy(stream);
     fem_plan_destroy(plan);
     fem_shard_destroy(shard);
+    stage[rank] = "finished";
   };
   std::vector<std::thread> threads;
   for (int rank = 0; rank < R; rank++) threads.emplace_back(body, rank);
   for (auto &t : threads) t.join();
+  if (watchdog.joinable()) {
+    { std::lock_guard<std::mutex> lock(wdMutex); wdDone = true; }
+    wdCv.notify_all();
+    watchdog.join();
+  }
   fem_dist_world_destroy(world);
   if (failed) return -1;
   if (o.debug) return 0;
@@ -395,7 +431,9 @@ int usage() {
                "                   inside this process instead (all ranks may share one GPU); --f64: fp64 plans;\n"
                "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering);\n"
                "                   --imex ITERS: semi-implicit steps (diffusion by ITERS CG iterations, dot products all-reduced\n"
-               "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2\n");
+               "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2;\n"
+               "                   --watchdog SECONDS: if the run has not finished by then, say where every rank is and exit 124\n"
+               "                   (FEM_DIST_TRACE=1: one stderr line per exchange stage)\n");
   return 2;
 }
 
@@ -413,7 +451,7 @@ int main(int argc, char **argv) {
     else if (a == "--host-constants") o.hostConstants = true;
     else if (a == "--f64") o.precision = FEM_PREC_F64;
     else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out" ||
-             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--dt-scale") {
+             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--dt-scale" || a == "--watchdog") {
       const char *v = value();
       if (!v) return usage();
       if (a == "-n") {
@@ -430,6 +468,7 @@ int main(int argc, char **argv) {
       else if (a == "--dump") o.dump = v;
       else if (a == "--imex") o.imex = std::atoi(v);
       else if (a == "--dt-scale") o.dtScale = std::atof(v);
+      else if (a == "--watchdog") o.watchdog = std::atof(v);
       else o.out = v;
     } else if (!a.empty() && a[0] == '-') return usage();
     else if (o.file.empty()) o.file = a;

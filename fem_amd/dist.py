@@ -320,7 +320,7 @@ class ShardedRun:
         lets the interior tiles run beside it; the ghost tiles are skipped there (the exchange
         overwrites them).  The first group after an exchange runs the interior tiles (they read
         no ghost row) before it waits for the exchange.
-        On the GPU the boundary tiles, the pack and the exchange go to a high-priority side stream
+        On the GPU the boundary tiles, the pack and the exchange go to a side stream
         and the interior tiles of the same group are launched on `stream` at once: the two launches
         share the chip (the few boundary workgroups are dispatched first, the interior ones fill the
         other slots) instead of a short boundary launch with its tail in front of the interior one."""
@@ -375,13 +375,15 @@ class ShardedRun:
             self._side_busy = False
 
     def _side_stream(self, stream):
-        """high-priority stream for the boundary tiles + pack + exchange of a group (None: CPU steppers,
-        the null stream, FEM_BOUNDARY_STREAM=0)"""
+        """stream for the boundary tiles + pack + exchange of a group (None: CPU steppers, the null stream,
+        FEM_BOUNDARY_STREAM=0).  Normal priority unless FEM_SIDE_PRIORITY=high: a high-priority stream that waits for
+        events of normal-priority streams stalled, now and then for good, when several host threads of one process
+        each had one (fem_amd/csrc/dist.cpp, tools/inproc_hang_probe.sh); the gain was 6.22x -> 6.25x in the rehearsal."""
         if stream is None or not isinstance(self.stepper, HipShardStepper) or os.environ.get("FEM_BOUNDARY_STREAM", "1") == "0":
             return None
         if getattr(self, "_side", None) is None:
             import torch
-            self._side = torch.cuda.Stream(priority=-1)
+            self._side = torch.cuda.Stream(priority=-1 if os.environ.get("FEM_SIDE_PRIORITY") == "high" else 0)
             self._ev_top, self._ev_side = torch.cuda.Event(), torch.cuda.Event()
             self._side_busy = False
         return self._side

@@ -40,6 +40,20 @@ def reference(sphere_off):
     return part, st.step(n0, c0, 0.1 * st.maxEdgeLen ** 2, 2 + 2 * ITER, fa.default_model().as_array())
 
 
+def run_fem(cmd, env=None):
+    """fem_run as a child process.  A run that does not finish says where it stopped instead of dying silently at the
+    time limit: --watchdog makes the program report every rank's stage and exit 124, FEM_DIST_TRACE adds one stderr
+    line per exchange stage, and the barrier of the in-process world gives up after 40 s."""
+    env = dict(os.environ if env is None else env)
+    env.update(FEM_DIST_TRACE="1", FEM_DIST_BARRIER_SECONDS="40")
+    try:
+        res = subprocess.run(cmd + ["--watchdog", "90"], capture_output=True, text=True, timeout=150, env=env)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail("fem_run did not finish: %s\n%s" % (" ".join(cmd), ((e.stderr or b"")[-3000:]).decode(errors="replace") if isinstance(e.stderr, bytes) else str(e.stderr)[-3000:]))
+    assert res.returncode == 0 and "Best time" in res.stdout, "exit %d\n%s\n%s" % (res.returncode, res.stdout[-1500:], res.stderr[-3000:])
+    return res
+
+
 def run_ranks(path, tmp_path, ranks, fuse, rings, transport, overlap=None, f64=True):
     dump = str(tmp_path / "state.bin")
     cmd = [FEM_RUN, path, "--ranks", str(ranks), "-n", str(NPARTS), "--fuse", str(fuse), "--rings", str(rings),
@@ -48,8 +62,7 @@ def run_ranks(path, tmp_path, ranks, fuse, rings, transport, overlap=None, f64=T
     env.pop("FEM_OVERLAP", None)
     if overlap is not None:
         env["FEM_OVERLAP"] = overlap
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=150, env=env)
-    assert res.returncode == 0 and "Best time" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
+    res = run_fem(cmd, env)
     raw = np.fromfile(dump)
     V = len(raw) // 2
     return raw[:V], raw[V:], res.stdout
@@ -97,8 +110,7 @@ def test_sharded_semi_implicit_steps(sphere_off, tmp_path, ranks, transport):
     dump = str(tmp_path / "imex.bin")
     cmd = [FEM_RUN, sphere_off, "--ranks", str(ranks), "-n", str(NPARTS), "--iterations", str(iters), "--seed", "3", "--transport", transport,
            "--imex", str(cg), "--dt-scale", str(scale), "--f64", "--dump", dump]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=150)
-    assert res.returncode == 0 and "Best time" in res.stdout, res.stdout[-1500:] + res.stderr[-1500:]
+    res = run_fem(cmd)
     raw = np.fromfile(dump)
     V = len(raw) // 2
     pts, tri, _ = fa.off_read(sphere_off)
