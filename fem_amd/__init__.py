@@ -55,6 +55,8 @@ lib.fem_error_string.restype = C.c_char_p
 lib.fem_error_detail.restype = C.c_char_p
 lib.fem_plan_operator_bytes.restype = C.c_uint64
 lib.fem_plan_operator_bytes.argtypes = [vp]
+lib.fem_plan_operator_format.restype = C.c_int
+lib.fem_plan_operator_format.argtypes = [vp]
 lib.fem_free.argtypes = [vp]
 lib.fem_plan_pack_halo.argtypes = [vp, C.c_uint64, vp]
 lib.fem_plan_pack_halo_from.argtypes = [vp, C.c_int, C.c_uint64, vp]
@@ -480,7 +482,9 @@ class Plan:
         _check(lib.fem_plan_tile_info(self.h, C.byref(k), C.byref(nt), C.byref(ml), C.byref(rows), C.byref(thr),
                                       C.byref(rpt)))
         return dict(ksteps=k.value, ntiles=nt.value, max_local=ml.value, rows_loaded=rows.value,
-                    threads=thr.value, rows_per_thread=rpt.value)
+                    threads=thr.value, rows_per_thread=rpt.value,
+                    operator_records="12-byte (fp32 weight + 3 x 21-bit gradient coefficients, per-row scale)"
+                    if self.operator_format() == 1 else "4 scalars")
 
     def pack_halo(self, dst_ptr, stream=None, which=0):
         """which = 0: from the current state buffer, 1: from the next one (see launch_tiles)"""
@@ -535,6 +539,10 @@ class Plan:
 
     def operator_bytes(self):
         return lib.fem_plan_operator_bytes(self.h)
+
+    def operator_format(self):
+        """0: four scalars per entry; 1: 12-byte records (fem_plan_operator_format)"""
+        return lib.fem_plan_operator_format(self.h)
 
     def state_ptr(self):
         p, nv, sb, bn, bc = C.c_uint64(), C.c_uint64(), C.c_int(), C.c_double(), C.c_double()

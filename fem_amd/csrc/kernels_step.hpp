@@ -203,12 +203,18 @@ constexpr bool tileOffsetsInLds(int rowsPerThread) { return rowsPerThread >= 4; 
 #endif
 constexpr bool kTileRowFence = FEM_TILE_ROW_FENCE != 0;
 
-template <typename T, int TPB, int R, int W, int MINW, int X, int PRO>
+// PK = 1 (fp32 plans without wide rows, FEM_TILE_PACKED): the operator stream in 12-byte records instead of 16 --
+// the Laplacian weight as it is (fp32) and the three gradient coefficients as 21-bit signed integers against a
+// per-row fp32 scale (row maximum / (2^20 - 1): a rounding error of at most 4.8e-7 of the row's largest
+// coefficient, 8 x an fp32 rounding), decoded once per launch into the same register rows.  coef then points at the
+// records (3 words each, at the entry offsets of the fp32 layout) and rscale at the scales (row_off / W + r).
+template <typename T, int TPB, int R, int W, int MINW, int X, int PRO, int PK = 0>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
     const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
-    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
+    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m, const float *__restrict__ rscale = nullptr) {
+  static_assert(!PK || (sizeof(T) == 4 && X != 2), "packed operator records: fp32 plans without wide rows");
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   extern __shared__ __align__(16) unsigned char tile_smem[];
@@ -229,13 +235,17 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   const uint t = threadIdx.x;
 
   // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
-  const T4 *__restrict__ tcoef = coef + roff;
+  const T4 *__restrict__ tcoef = PK ? coef : coef + roff;
+  const uint *__restrict__ tpk = reinterpret_cast<const uint *>(coef) + 3 * (size_t)roff;     // PK: 12-byte records
+  const float *__restrict__ trs = PK ? rscale + roff / W : nullptr;                            // PK: per-row scales
   const uint *__restrict__ tidx = idx2 + (roff >> 1);
   // Every load below is unconditional with a clamped index (no branch => no wait at a branch
   // merge), so the whole prologue is in flight at once: R*(W + W/2) operator loads, then the
   // ghost ids, then the state gathers; the first wait is the one in front of the LDS writes.
   T4 cf[R][W];
   uint ix[R][W / 2];
+  uint pk[PK ? R : 1][PK ? W : 1][3];
+  float rs[PK ? R : 1];
   constexpr int SU = 4;                                  // state slots per thread per pass
   uint gi[SU];
   auto loadGhostIds = [&](uint i0) {
@@ -290,11 +300,26 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     for (int w = 0; w < W / 2; w++)                      // ids < 4096: both halves scale
       ix[q][w] = (PRO == 3 ? __builtin_nontemporal_load(&tidx[w * rpad + r]) : tidx[w * rpad + r]) * (uint)sizeof(T2);
   }
+  if constexpr (PK) {
 #pragma unroll
-  for (int q = 0; q < R; q++) {
-    const uint r = min(t + TPB * q, rpad - 1);
+    for (int q = 0; q < R; q++) {
+      const uint r = min(t + TPB * q, rpad - 1);
 #pragma unroll
-    for (int w = 0; w < W; w++) cf[q][w] = PRO >= 2 ? ntload(&tcoef[w * rpad + r]) : tcoef[w * rpad + r];
+      for (int w = 0; w < W; w++) {
+        const uint *rec = tpk + 3 * (w * rpad + r);
+#pragma unroll
+        for (int d = 0; d < 3; d++) pk[q][w][d] = PRO >= 2 ? __builtin_nontemporal_load(rec + d) : rec[d];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) rs[q] = PRO >= 2 ? __builtin_nontemporal_load(&trs[min(t + TPB * q, rpad - 1)]) : trs[min(t + TPB * q, rpad - 1)];
+  } else {
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const uint r = min(t + TPB * q, rpad - 1);
+#pragma unroll
+      for (int w = 0; w < W; w++) cf[q][w] = PRO >= 2 ? ntload(&tcoef[w * rpad + r]) : tcoef[w * rpad + r];
+    }
   }
   if (X == 1 && xcnt) {                                  // tile-uniform; see X == 2 above
     for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];      // first extra | count << 16 per row
@@ -322,6 +347,21 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
       const uint i = i0 + t + TPB * u;
       if (i < mk) cur[i] = sv[u];
     }
+  }
+  if constexpr (PK) {
+    // decode the records into the register rows (all loads have landed: the state writes above waited for the
+    // gathers, which were issued last)
+#pragma unroll
+    for (int q = 0; q < R; q++)
+#pragma unroll
+      for (int w = 0; w < W; w++) {
+        const uint a = pk[q][w][1], b2 = pk[q][w][2];
+        const int qx = (int)(a << 11) >> 11;                                        // bits  0..20
+        const int qy = (int)(__builtin_amdgcn_alignbit(b2, a, 21) << 11) >> 11;      // bits 21..41
+        const int qz = (int)(b2 << 1) >> 11;                                        // bits 42..62
+        cf[q][w].x = __uint_as_float(pk[q][w][0]);
+        cf[q][w].y = (T)((float)qx * rs[q]); cf[q][w].z = (T)((float)qy * rs[q]); cf[q][w].w = (T)((float)qz * rs[q]);
+      }
   }
   __syncthreads();
 

@@ -52,8 +52,8 @@ class SingleRun:
     def traffic_key(self):
         """what a PMC pass is valid for: kernel, precision, rows, fused depth, register tile, partition count"""
         ti = self.plan.tile_info()
-        return "%s:%s:%d:k%d:%dx%d:p%d" % (self.kernel_name, self.precision, self.V, ti["ksteps"], ti["threads"],
-                                            ti["rows_per_thread"], self.part.n)
+        return "%s:%s:%d:k%d:%dx%d:p%d%s" % (self.kernel_name, self.precision, self.V, ti["ksteps"], ti["threads"],
+                                              ti["rows_per_thread"], self.part.n, ":rec12" if self.plan.operator_format() == 1 else "")
 
     def measured_traffic(self):
         """(HBM bytes per launch, source tag) from the rocprofv3 PMC passes committed under profiles/ --

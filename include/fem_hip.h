@@ -363,6 +363,13 @@ int fem_plan_state(const fem_plan *p, uint64_t *dev_ptr, uint64_t *n_vertices, i
                    double *base_n, double *base_c);
 /* operator footprint in device memory (bytes read per step, excluding state) */
 uint64_t fem_plan_operator_bytes(const fem_plan *p);
+/* How the plan stores an operator entry (no counterpart in the reference, whose kernel reads its own layout):
+ * 0 = four scalars of the plan's precision (w, Cx, Cy, Cz);
+ * 1 = 12-byte records: w in fp32 and Cx, Cy, Cz as 21-bit signed integers against a per-row fp32 scale (rounding
+ *     error at most 4.8e-7 of the row's largest gradient coefficient).  Default for fused fp32 plans without rows
+ *     wider than 6 entries whose operator comes from the host assembly; FEM_TILE_PACKED=0 in the environment at plan
+ *     creation keeps format 0.  fem_plan_download_coef returns the decoded values either way. */
+int fem_plan_operator_format(const fem_plan *p);
 
 /* ------------------------------------------------------------------ */
 /* 5. Sharding over the GPUs of one node (no counterpart in the         */

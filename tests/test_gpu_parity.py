@@ -494,6 +494,51 @@ def test_timed_configuration_vs_oracle(cfg, ksteps, prec, monkeypatch):
         assert not np.array_equal(n_gpu, n0)
 
 
+@pytest.mark.parametrize("cfg,ksteps", [(8, 7), (2, 6)])
+def test_packed_operator_records(cfg, ksteps, monkeypatch):
+    """12-byte operator records (fp32 weight + three 21-bit gradient coefficients against a per-row scale), the default
+    of fused fp32 plans without wide rows: the decoded coefficients are within 2^-21 of the row's largest gradient
+    coefficient of the fp32 ones and the weights are bit-equal; the run agrees with the fp32-record plan to 1e-8 (a
+    thousandth of the tolerance), is no further from the f64 oracle than that plan, and within the fp32 tolerance; plans that
+    cannot use them (wide rows, f64, device assembly) keep four scalars"""
+    from helpers import Case
+    monkeypatch.setenv("FEM_TILE_CONFIG", str(cfg))
+    monkeypatch.setenv("FEM_TILE_PROLOGUE", "3")
+    pts, tri = fa.make_icosphere(64, 0.1)
+    case = Case(pts, tri, max(2, len(pts) // _TIMED_N0[cfg][ksteps]))
+    case.mesh.init_stats(fa.PREC_F64)
+    packed = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps)
+    monkeypatch.setenv("FEM_TILE_PACKED", "0")
+    plain = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps)
+    monkeypatch.delenv("FEM_TILE_PACKED")
+    assert packed.operator_format() == 1 and plain.operator_format() == 0
+    assert packed.operator_bytes() < 0.86 * plain.operator_bytes()
+    a, b = packed.coef(), plain.coef()
+    assert a.shape == b.shape and np.array_equal(a[:, 0], b[:, 0])
+    big = np.abs(b[:, 1:]).max()
+    assert np.abs(a[:, 1:] - b[:, 1:]).max() <= big * 2.0 ** -21 * 1.01 and np.abs(a[:, 1:] - b[:, 1:]).max() > 0
+    steps = 14 * ksteps + 3
+    n0, c0 = case.n0.astype(np.float32).astype(np.float64), case.c0.astype(np.float32).astype(np.float64)
+    out = []
+    for plan in (packed, plain):
+        plan.set_state(n0, c0)
+        plan.run(steps, case.dt, case.model)
+        out.append(plan.get_state())
+    n_ref, c_ref = case.ostats(ol.F64).step(n0, c0, case.dt, steps, case.model.as_array())
+    e_packed, e_plain = rel_l2(out[0][0], n_ref), rel_l2(out[1][0], n_ref)
+    assert e_packed <= TOL_F32 and rel_l2(out[0][1], c_ref) <= TOL_F32
+    # observed: packed vs fp32 records 2e-9, either against the oracle 2.4e-9 (1M vertices, 25..3200 steps: 1e-9..3e-9
+    # between the two, 1e-8..2e-7 against the oracle for both, equal to four digits: tests/report_packed_accuracy.py)
+    assert rel_l2(out[0][0], out[1][0]) <= 1e-8 and e_packed <= 2 * e_plain + 1e-9, (e_packed, e_plain, rel_l2(out[0][0], out[1][0]))
+    # plans that keep four scalars per entry
+    assert fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps).operator_format() == 0
+    assert fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps, assemble=True).operator_format() == 0
+    wp, wt = fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01)
+    wide = Case(wp, wt, max(2, len(wp) // 700))
+    wide.mesh.init_stats(fa.PREC_F64)
+    assert fa.Plan(wide.mesh, fa.PREC_F32, part=wide.part, ksteps=5).operator_format() == 0
+
+
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_fused_plan_on_multilevel_partition(prec):
     """the METIS-style R0 stage (multilevel k-way on the dual graph: parts of unequal size, some needing a split to
