@@ -301,18 +301,24 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
       ix[q][w] = (PRO == 3 ? __builtin_nontemporal_load(&tidx[w * rpad + r]) : tidx[w * rpad + r]) * (uint)sizeof(T2);
   }
   if constexpr (PK) {
+    // scalar base of every entry slot + one 32-bit byte offset per row: the loads take the (SGPR base, VGPR offset)
+    // form, no 64-bit address pair per load
 #pragma unroll
     for (int q = 0; q < R; q++) {
-      const uint r = min(t + TPB * q, rpad - 1);
+      const uint boff = min(t + TPB * q, rpad - 1) * 12u;
 #pragma unroll
       for (int w = 0; w < W; w++) {
-        const uint *rec = tpk + 3 * (w * rpad + r);
+        const unsigned char *slot = reinterpret_cast<const unsigned char *>(tpk + 3 * (size_t)(w * rpad));
+        const uint *rec = reinterpret_cast<const uint *>(slot + boff);
 #pragma unroll
         for (int d = 0; d < 3; d++) pk[q][w][d] = PRO >= 2 ? __builtin_nontemporal_load(rec + d) : rec[d];
       }
     }
 #pragma unroll
-    for (int q = 0; q < R; q++) rs[q] = PRO >= 2 ? __builtin_nontemporal_load(&trs[min(t + TPB * q, rpad - 1)]) : trs[min(t + TPB * q, rpad - 1)];
+    for (int q = 0; q < R; q++) {
+      const float *rp = reinterpret_cast<const float *>(reinterpret_cast<const unsigned char *>(trs) + min(t + TPB * q, rpad - 1) * 4u);
+      rs[q] = PRO >= 2 ? __builtin_nontemporal_load(rp) : *rp;
+    }
   } else {
 #pragma unroll
     for (int q = 0; q < R; q++) {
