@@ -111,8 +111,7 @@ struct fem_plan {
   uint64_t tile_bytes = 0;
   DevBuf<fem_uint> tmeta, tghost, tidx2, txinfo;
   void *tcoef = nullptr;
-  bool packed = false;                 // fused fp32 plans without wide rows: 12-byte operator records (kernels_step.hpp, PK)
-  float *trscale = nullptr;            // ... and their per-row scales
+  bool packed = false;                 // fused fp32 plans: 12-byte operator records (kernels_step.hpp, PK)
   // device assembly (FEM_PLAN_DEVICE_ASSEMBLY): connectivity SoA, positions, per-face records, entry tables
   bool can_assemble = false;
   bool fan_rows = false;            // every row is one fan in order: assemble_row_fan applies
@@ -236,7 +235,9 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   };
   auto kern = p->maxExtra ? pick(std::integral_constant<int, 2>()) : pick(std::integral_constant<int, 1>());
   if constexpr (sizeof(T) == 4 && (C == kDefaultTileCfg || C == kDefaultTileCfgWide)) {
-    if (p->packed) kern = pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 3, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 1, 1>;
+    if (p->packed)
+      kern = p->maxExtra ? (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 3, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 1, 1>)
+                         : (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 3, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 1, 1>);
   }
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
                      (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
@@ -247,7 +248,7 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   if (count == 0) return hipSuccess;
   hipLaunchKernelGGL(kern, dim3(count), dim3(TPB), lds, stream, (const T2 *)src, (T2 *)dst, p->tmeta.p,
                      p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->txinfo.p, first, count, p->maxLocal, p->maxExtra,
-                     nsteps, m, (const float *)p->trscale);
+                     nsteps, m);
   return hipSuccess;
 }
 
@@ -513,7 +514,6 @@ void fem_plan_destroy(fem_plan *p) {
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   for (void *q : {p->mass, p->wsum, p->ix_w, p->ix_r, p->ix_p, p->ix_q, (void *)p->ix_partial, (void *)p->ix_sc}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
-  if (p->trscale) (void)hipFree(p->trscale);
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
   delete p;
@@ -625,29 +625,34 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     ok(p->tghost.alloc(TL.ghost.size())) && (TL.ghost.empty() || ok(p->tghost.upload(TL.ghost.data()))) &&
     ok(p->tidx2.alloc(TL.idx2.size())) && ok(p->tidx2.upload(TL.idx2.data())) &&
     ok(p->txinfo.alloc(TL.xinfo.size())) && ok(p->txinfo.upload(TL.xinfo.data()));
-    // 12-byte operator records (FEM_TILE_PACKED, default on): fp32 plans of the two default tile geometries with
-    // no wide rows anywhere (then every tile's entry offset is a multiple of W, which is how the kernel finds the
-    // row scales) whose operator comes from the host assembly
+    // 12-byte operator records (FEM_TILE_PACKED, default on): fp32 plans of the two default tile geometries whose
+    // operator comes from the host assembly.  The array keeps the four-float layout's size and tile offsets
+    // (kernels_step.hpp, PK): per tile W * rows_pad records, then rows_pad scales; extras stay four floats.
     const char *pkEnv = getenv("FEM_TILE_PACKED");
-    bool packed = precision == FEM_PREC_F32 && TL.maxExtra == 0 && !(flags & FEM_PLAN_DEVICE_ASSEMBLY) &&
+    bool packed = precision == FEM_PREC_F32 && !(flags & FEM_PLAN_DEVICE_ASSEMBLY) &&
                   (tcfg == kDefaultTileCfg || tcfg == kDefaultTileCfgWide) && !(pkEnv && !strcmp(pkEnv, "0"));
-    for (fem::uint t = 0; t < TL.ntiles && packed; t++) packed = TL.meta[16 * (size_t)t + 2] % kTileW == 0;
     if (packed) {
       const size_t entries = TL.coef.size() / 4;
-      std::vector<fem::uint> rec(3 * entries, 0u);
-      std::vector<float> scale(entries / kTileW, 0.0f);
+      std::vector<float> c32(TL.coef.begin(), TL.coef.end());
+      fem::uint *words = reinterpret_cast<fem::uint *>(c32.data());
       constexpr int kQ = (1 << 20) - 1;
+      std::vector<unsigned char> badTile(TL.ntiles, 0);      // a coefficient that is not finite (degenerate triangles): keep four floats, NaN and all
+      uint64_t recWords = 0, scaleWords = 0;
+      for (fem::uint t = 0; t < TL.ntiles; t++) { recWords += (uint64_t)kTileW * TL.meta[16 * (size_t)t + 3]; scaleWords += TL.meta[16 * (size_t)t + 3]; }
       fem::parallelFor(TL.ntiles, 64, [&](size_t t0, size_t t1) {
+        std::vector<fem::uint> block;
         for (size_t t = t0; t < t1; t++) {
           const size_t roff = TL.meta[16 * t + 2], rpad = TL.meta[16 * t + 3];
+          block.assign(4 * (size_t)kTileW * rpad, 0u);
           for (size_t r = 0; r < rpad; r++) {
             double big = 0;
             for (size_t w = 0; w < (size_t)kTileW; w++)
               for (int d = 1; d < 4; d++) big = std::max(big, std::fabs(TL.coef[4 * (roff + w * rpad + r) + d]));
-            const float sc = (float)(big / kQ);
-            scale[roff / kTileW + r] = sc;
+            if (!std::isfinite(big)) badTile[t] = 1;
+            const float sc = std::isfinite(big) ? (float)(big / kQ) : 0.0f;
+            memcpy(&block[3 * (size_t)kTileW * rpad + r], &sc, 4);
             for (size_t w = 0; w < (size_t)kTileW; w++) {
-              const size_t e = roff + w * rpad + r;
+              const size_t e = roff + w * rpad + r, le = w * rpad + r;
               const float wt = (float)TL.coef[4 * e];
               fem::uint q[3] = {0, 0, 0};
               for (int d = 0; d < 3; d++) {
@@ -655,23 +660,25 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
                 v = std::max<long>(-kQ, std::min<long>(kQ, v));
                 q[d] = (fem::uint)v & 0x1fffffu;
               }
-              memcpy(&rec[3 * e], &wt, 4);
-              rec[3 * e + 1] = q[0] | (q[1] << 21);
-              rec[3 * e + 2] = (q[1] >> 11) | (q[2] << 10);
+              memcpy(&block[3 * le], &wt, 4);
+              block[3 * le + 1] = q[0] | (q[1] << 21);
+              block[3 * le + 2] = (q[1] >> 11) | (q[2] << 10);
             }
           }
+          memcpy(words + 4 * roff, block.data(), 4 * block.size());
         }
       });
-      ok(hipMalloc(&p->tcoef, 4 * std::max<size_t>(rec.size(), 4))) &&
-      ok(hipMemcpy(p->tcoef, rec.data(), 4 * rec.size(), hipMemcpyHostToDevice)) &&
-      ok(hipMalloc((void **)&p->trscale, 4 * std::max<size_t>(scale.size(), 1))) &&
-      ok(hipMemcpy(p->trscale, scale.data(), 4 * scale.size(), hipMemcpyHostToDevice));
-      p->packed = true;
-      p->tile_bytes -= (uint64_t)entries * 4;              // 12-byte records ...
-      p->tile_bytes += (uint64_t)scale.size() * 4;         // ... and one scale per row
-    } else {
-      uploadCoef(&p->tcoef, TL.coef);
+      for (unsigned char b : badTile) if (b) packed = false;
+      if (packed) {
+        ok(hipMalloc(&p->tcoef, 4 * std::max<size_t>(c32.size(), 4))) &&
+        ok(hipMemcpy(p->tcoef, c32.data(), 4 * c32.size(), hipMemcpyHostToDevice));
+        p->packed = true;
+        p->tile_bytes -= recWords * 4;                       // 12-byte records ...
+        p->tile_bytes += scaleWords * 4;                     // ... and one scale per row
+        (void)entries;
+      }
     }
+    if (!packed) uploadCoef(&p->tcoef, TL.coef);
   } else {
     p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4; p->entries = L.idx.size();
     ok(p->slice_off.alloc(L.slice_off.size())) && ok(p->slice_off.upload(L.slice_off.data())) &&
@@ -1030,22 +1037,23 @@ int fem_plan_download_coef(fem_plan *p, double *out) {
   const void *dev = p->ksteps > 0 ? p->tcoef : p->coef;
   const size_t n = fem_plan_coef_count(p);
   if (p->packed) {                     // 12-byte records: decoded the way the kernel decodes them
-    const size_t entries = n / 4;
-    std::vector<fem_uint> rec(3 * entries), meta(16 * (size_t)p->ntiles);
-    std::vector<float> scale(entries / kTileW);
+    std::vector<float> c32(n);
+    std::vector<fem_uint> meta(16 * (size_t)p->ntiles);
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(rec.data(), dev, 4 * rec.size(), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(scale.data(), p->trscale, 4 * scale.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(c32.data(), dev, 4 * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(meta.data(), p->tmeta.p, 4 * meta.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) out[i] = c32[i];       // extras of wide rows: four floats as they are
+    const fem_uint *words = reinterpret_cast<const fem_uint *>(c32.data());
     for (size_t t = 0; t < p->ntiles; t++) {
       const size_t roff = meta[16 * t + 2], rpad = meta[16 * t + 3];
+      const fem_uint *block = words + 4 * roff;
       for (size_t w = 0; w < (size_t)kTileW; w++)
         for (size_t r = 0; r < rpad; r++) {
-          const size_t e = roff + w * rpad + r;
-          const fem_uint a = rec[3 * e + 1], b = rec[3 * e + 2];
-          float wt;
-          memcpy(&wt, &rec[3 * e], 4);
-          const float sc = scale[roff / kTileW + r];
+          const size_t e = roff + w * rpad + r, le = w * rpad + r;
+          const fem_uint a = block[3 * le + 1], b = block[3 * le + 2];
+          float wt, sc;
+          memcpy(&wt, &block[3 * le], 4);
+          memcpy(&sc, &block[3 * (size_t)kTileW * rpad + r], 4);
           const int qx = (int)(a << 11) >> 11, qy = (int)(((a >> 21) | (b << 11)) << 11) >> 11, qz = (int)(b << 1) >> 11;
           out[4 * e] = wt; out[4 * e + 1] = (float)qx * sc; out[4 * e + 2] = (float)qy * sc; out[4 * e + 3] = (float)qz * sc;
         }

@@ -203,18 +203,19 @@ constexpr bool tileOffsetsInLds(int rowsPerThread) { return rowsPerThread >= 4; 
 #endif
 constexpr bool kTileRowFence = FEM_TILE_ROW_FENCE != 0;
 
-// PK = 1 (fp32 plans without wide rows, FEM_TILE_PACKED): the operator stream in 12-byte records instead of 16 --
-// the Laplacian weight as it is (fp32) and the three gradient coefficients as 21-bit signed integers against a
-// per-row fp32 scale (row maximum / (2^20 - 1): a rounding error of at most 4.8e-7 of the row's largest
-// coefficient, 8 x an fp32 rounding), decoded once per launch into the same register rows.  coef then points at the
-// records (3 words each, at the entry offsets of the fp32 layout) and rscale at the scales (row_off / W + r).
+// PK = 1 (fp32 plans whose operator comes from the host assembly, FEM_TILE_PACKED): the operator stream in 12-byte
+// records instead of 16 -- the Laplacian weight as it is (fp32) and the three gradient coefficients as 21-bit signed
+// integers against a per-row fp32 scale (row maximum / (2^20 - 1): a rounding error of at most 4.8e-7 of the row's
+// largest coefficient, 8 x an fp32 rounding), decoded once per launch into the same register rows.  A tile's block
+// keeps its place and size in the coefficient array (16 bytes per entry from row_off on): the W * rows_pad records
+// fill its first three quarters, the rows_pad scales follow; the extras of wide rows stay four floats behind the block.
 template <typename T, int TPB, int R, int W, int MINW, int X, int PRO, int PK = 0>
 __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
     const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
-    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m, const float *__restrict__ rscale = nullptr) {
-  static_assert(!PK || (sizeof(T) == 4 && X != 2), "packed operator records: fp32 plans without wide rows");
+    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
+  static_assert(!PK || sizeof(T) == 4, "packed operator records: fp32 plans");
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   extern __shared__ __align__(16) unsigned char tile_smem[];
@@ -235,9 +236,9 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   const uint t = threadIdx.x;
 
   // tile-uniform (scalar) bases + 32-bit lane offsets keep the address arithmetic out of VGPRs
-  const T4 *__restrict__ tcoef = PK ? coef : coef + roff;
-  const uint *__restrict__ tpk = reinterpret_cast<const uint *>(coef) + 3 * (size_t)roff;     // PK: 12-byte records
-  const float *__restrict__ trs = PK ? rscale + roff / W : nullptr;                            // PK: per-row scales
+  const T4 *__restrict__ tcoef = coef + roff;
+  const uint *__restrict__ tpk = reinterpret_cast<const uint *>(tcoef);                        // PK: 12-byte records ...
+  const float *__restrict__ trs = reinterpret_cast<const float *>(tpk + 3 * (size_t)(W * rpad));   // ... then the row scales
   const uint *__restrict__ tidx = idx2 + (roff >> 1);
   // Every load below is unconditional with a clamped index (no branch => no wait at a branch
   // merge), so the whole prologue is in flight at once: R*(W + W/2) operator loads, then the

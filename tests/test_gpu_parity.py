@@ -500,7 +500,7 @@ def test_packed_operator_records(cfg, ksteps, monkeypatch):
     of fused fp32 plans without wide rows: the decoded coefficients are within 2^-21 of the row's largest gradient
     coefficient of the fp32 ones and the weights are bit-equal; the run agrees with the fp32-record plan to 1e-8 (a
     thousandth of the tolerance), is no further from the f64 oracle than that plan, and within the fp32 tolerance; plans that
-    cannot use them (wide rows, f64, device assembly) keep four scalars"""
+    cannot use them (f64, device assembly) keep four scalars; meshes with wide rows keep four floats for the extras only"""
     from helpers import Case
     monkeypatch.setenv("FEM_TILE_CONFIG", str(cfg))
     monkeypatch.setenv("FEM_TILE_PROLOGUE", "3")
@@ -533,10 +533,29 @@ def test_packed_operator_records(cfg, ksteps, monkeypatch):
     # plans that keep four scalars per entry
     assert fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps).operator_format() == 0
     assert fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps, assemble=True).operator_format() == 0
+    # rows wider than the register tile's six entries: their first six entries in records, the rest four floats
     wp, wt = fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01)
     wide = Case(wp, wt, max(2, len(wp) // 700))
     wide.mesh.init_stats(fa.PREC_F64)
-    assert fa.Plan(wide.mesh, fa.PREC_F32, part=wide.part, ksteps=5).operator_format() == 0
+    st = wide.ostats(ol.F64)
+    dt = min(wide.dt, stable_dt(st, wide.model))
+    n0, c0 = smooth_ic(wide.pts)
+    n0, c0 = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+    wplan = fa.Plan(wide.mesh, fa.PREC_F32, part=wide.part, ksteps=5)
+    monkeypatch.setenv("FEM_TILE_PACKED", "0")
+    wplain = fa.Plan(wide.mesh, fa.PREC_F32, part=wide.part, ksteps=5)
+    monkeypatch.delenv("FEM_TILE_PACKED")
+    assert wplan.operator_format() == 1 and wplain.operator_format() == 0
+    a, b = wplan.coef(), wplain.coef()
+    assert np.array_equal(a[:, 0], b[:, 0]) and np.abs(a[:, 1:] - b[:, 1:]).max() <= np.abs(b[:, 1:]).max() * 2.0 ** -21 * 1.01
+    res = []
+    for plan in (wplan, wplain):
+        plan.set_state(n0, c0)
+        plan.run(33, dt, wide.model)
+        res.append(plan.get_state())
+    n_ref, c_ref = st.step(n0, c0, dt, 33, wide.model.as_array())
+    assert rel_l2(res[0][0], n_ref) <= TOL_F32 and rel_l2(res[0][1], c_ref) <= TOL_F32
+    assert rel_l2(res[0][0], res[1][0]) <= 1e-7, rel_l2(res[0][0], res[1][0])
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
