@@ -80,6 +80,7 @@ class Barrier {
   double limit_ = 60.0;
 };
 
+const int g_failRank = getenv("FEM_DIST_TEST_FAIL_RANK") ? atoi(getenv("FEM_DIST_TEST_FAIL_RANK")) : -1;
 const bool g_trace = getenv("FEM_DIST_TRACE") && strcmp(getenv("FEM_DIST_TRACE"), "0") != 0;   // one stderr line per stage
 #define TRACE(d, ...)                                              \
   do {                                                             \
@@ -165,6 +166,8 @@ const bool g_inprocEvents = !(getenv("FEM_DIST_INPROC") && !strcmp(getenv("FEM_D
 
 int startExchange(fem_dist *d, int which, hipStream_t stream, uint64_t vec = 0) {     // vec != 0: that vector instead of a state buffer
   TRACE(d, "exchange %d: begin", d->nExchanges);
+  if (g_failRank == d->rank && d->nExchanges >= 1)        // fault injection for the tests (FEM_DIST_TEST_FAIL_RANK)
+    return fail(FEM_ERR_DEVICE, "injected failure of rank " + std::to_string(d->rank) + " (FEM_DIST_TEST_FAIL_RANK)");
   if (d->world) {
     // the previous exchange's copies out of every send buffer must be done before it is packed again
     if (!g_inprocEvents && d->everExchanged) {

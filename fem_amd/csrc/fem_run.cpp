@@ -163,7 +163,7 @@ double gpuRun(int n, const Options &o, const fem_model &model, const Run &r) {
   if (!ok(fem_ref_layout_create(r.ordered, n, r.nodeParts.data(), r.elementParts.data(), &lay), "initializeGPUData")) return -1;
   const int rc = fem_ref_device_create(lay, r.nodeParts.data(), r.V, &dev);
   fem_ref_layout_destroy(lay);
-  if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -1; }      // main.cpp:357-364
+  if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -2; }      // main.cpp:357-364: the loop goes on
   if (!ok(rc, "GPUrun")) return -1;
 
   std::vector<fem_double2> fn(r.V);
@@ -222,7 +222,7 @@ double nativeRun(int n, const Options &o, const fem_model &model, const Run &r) 
   fem_plan *plan = nullptr;
   const int rc = o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), nullptr, FEM_PREC_F32, &model, o.fuse, &plan)
                             : fem_plan_create(r.ordered, FEM_PREC_F32, &model, &plan);
-  if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -1; }
+  if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -2; }
   if (!ok(rc, "plan")) return -1;
   double usPerStep = -1;
   do {
@@ -490,14 +490,15 @@ int main(int argc, char **argv) {
   if (o.native && !partsGiven) o.startN = o.endN = std::max(1, V / o.rowsPerPart);
 
   double bestTime = 0;
-  int bestN = -1;
+  int bestN = -1, failedRuns = 0;
   for (int n = o.startN; n <= o.endN; n++) {
     Run r;
     if (!initializeData(original, n, o, model, r)) { fem_mesh_destroy(original); return 1; }
     const double t = o.ranks > 0 ? shardedRun(n, o, model, r) : (o.native ? nativeRun(n, o, model, r) : gpuRun(n, o, model, r));
     if ((bestN == -1 || bestTime > t) && t > 0) { bestN = n; bestTime = t; }
+    if (t < 0 && t > -1.5) failedRuns++;       // -2: this partition count exceeds the size limits (as the reference, not a failure)
   }
-  if (!o.debug) std::printf("Best time with %d partitions is %.1f!\n", bestN, bestTime);
+  if (!o.debug) std::printf("Best time with %d partitions is %.1f!\n", bestN, bestTime);      // also with bestN = -1, as the reference
   fem_mesh_destroy(original);
-  return 0;
+  return failedRuns ? 1 : 0;                 // a run that failed has said why on stderr
 }

@@ -125,3 +125,16 @@ def test_sharded_semi_implicit_steps(sphere_off, tmp_path, ranks, transport):
     n_ref, c_ref = plan.get_state()
     assert V == om.V and not np.array_equal(n_ref, n0)
     assert rel_l2(raw[:V], n_ref) <= 1e-10 and rel_l2(raw[V:], c_ref) <= 1e-10
+
+
+def test_failing_rank_does_not_hang_the_others(sphere_off, tmp_path):
+    """a rank whose exchange fails (injected: FEM_DIST_TEST_FAIL_RANK) breaks the in-process barrier: the other ranks
+    return an error at once instead of waiting for it, and the program exits non-zero with both messages"""
+    import time
+    cmd = [FEM_RUN, sphere_off, "--ranks", "3", "-n", str(NPARTS), "--fuse", "4", "--rings", "4", "--iterations", str(ITER), "--seed", "3",
+           "--transport", "inproc", "--f64", "--watchdog", "60"]
+    env = dict(os.environ, FEM_DIST_TEST_FAIL_RANK="1", FEM_DIST_BARRIER_SECONDS="30")
+    t0 = time.time()
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
+    assert res.returncode not in (0, 124) and time.time() - t0 < 25, (res.returncode, res.stderr[-2000:])
+    assert "injected failure of rank 1" in res.stderr and "barrier broken" in res.stderr, res.stderr[-2000:]
