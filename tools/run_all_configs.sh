@@ -3,7 +3,7 @@
 # The five BASELINE.md configurations on one GPU, one JSON line each (appended as they finish).
 OUT=${1:-gpurun_out/configs.jsonl}
 : > $OUT
-run() { echo "== $*" >&2; timeout -k 10 400 "$@" 2>/dev/null | tail -1 >> $OUT || echo "{\"failed\": \"$*\"}" >> $OUT; tail -c 300 $OUT >&2; echo >&2; }
+run() { echo "== $*" >&2; PYTHONPATH=. timeout -k 10 400 "$@" 2>/dev/null | tail -1 >> $OUT || echo "{\"failed\": \"$*\"}" >> $OUT; tail -c 300 $OUT >&2; echo >&2; }
 run python bench.py --workload sphere10k --steps 2000 --no-cpu-baseline            # config 1, fused
 run python bench.py --workload sphere10k --steps 2000 --fuse 0 --no-cpu-baseline   # config 1, single-step kernel
 run python tools/bench_ref_step.py 32 197 2000                                     # config 1, drop-in step()
@@ -13,7 +13,9 @@ run python bench.py --workload sphere16m --steps 1000                           
 run python bench.py --workload sphere16m --steps 400 --fuse 0 --no-cpu-baseline
 run python bench.py --workload scan8m --steps 400 --no-cpu-baseline                # config 4
 run python bench.py --workload scan8m --steps 200 --fuse 0 --no-cpu-baseline
-run python tools/bench_assembly.py 640 200 sell                                    # config 5
+run python bench.py --workload deform4m --steps 200 --no-cpu-baseline              # config 5 as the loop (fused assembly-and-step)
+run python bench.py --workload sphere16m --steps 1000 --precision f64 --no-cpu-baseline   # config 3 in the reference's arithmetic type
+run python tools/bench_assembly.py 640 200 sell                                    # config 5, the kernels apart
 run python tools/bench_assembly.py 640 200 tile
 run python tools/bench_ref_step.py 640 250 100                                     # drop-in step() at 4M
 run python tools/bench_imex.py 640 20 20 10                                        # semi-implicit stepping
