@@ -18,7 +18,11 @@ from helpers import rel_l2, scan_case, smooth_ic, sphere_case, stable_dt, strip_
 
 pytestmark = pytest.mark.gpu
 
-TOL_REF = 1e-8
+# drop-in step() against the oracle's MIXED mode: the reference keeps the half-edge gradients and their products in fp32
+# (float4 he_grads, FEM_common.cu:104-132), so the two sides agree only up to how the compiler contracts those fp32
+# multiply-adds (nvcc and hipcc both do by default; the oracle is C without contraction): observed 2e-10 .. 1.4e-8
+# (the largest on the single-triangle mesh, where nothing averages out)
+TOL_REF = 3e-8
 TOL_F64 = 1e-11
 TOL_F32 = 1e-5
 
