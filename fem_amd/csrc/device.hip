@@ -111,7 +111,8 @@ struct fem_plan {
   uint64_t tile_bytes = 0;
   DevBuf<fem_uint> tmeta, tghost, tidx2, txinfo;
   void *tcoef = nullptr;
-  bool packed = false;                 // fused fp32 plans: 12-byte operator records (kernels_step.hpp, PK)
+  bool packed = false;                 // fp32 plans: 12-byte operator records (kernels_step.hpp, PK)
+  float *rscale = nullptr;             // ... of a sliced-ELL plan: the row scales (a fused plan keeps them inside its tile blocks)
   // device assembly (FEM_PLAN_DEVICE_ASSEMBLY): connectivity SoA, positions, per-face records, entry tables
   bool can_assemble = false;
   bool fan_rows = false;            // every row is one fan in order: assemble_row_fan applies
@@ -514,6 +515,7 @@ void fem_plan_destroy(fem_plan *p) {
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   for (void *q : {p->mass, p->wsum, p->ix_w, p->ix_r, p->ix_p, p->ix_q, (void *)p->ix_partial, (void *)p->ix_sc}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
+  if (p->rscale) (void)hipFree(p->rscale);
   if (p->coef) (void)hipFree(p->coef);
   for (void *s : p->state) if (s) (void)hipFree(s);
   delete p;
@@ -683,7 +685,51 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4; p->entries = L.idx.size();
     ok(p->slice_off.alloc(L.slice_off.size())) && ok(p->slice_off.upload(L.slice_off.data())) &&
     ok(p->idx.alloc(L.idx.size())) && ok(p->idx.upload(L.idx.data()));
-    uploadCoef(&p->coef, L.coef);
+    // 12-byte operator records (FEM_TILE_PACKED, default on) for fp32 plans whose operator comes from the host
+    // assembly and that do no implicit stepping (whose kernels read the weights out of four-float entries)
+    const char *pkEnv = getenv("FEM_TILE_PACKED");
+    bool packed = precision == FEM_PREC_F32 && flags == 0 && !L.idx.empty() && !(pkEnv && !strcmp(pkEnv, "0"));
+    if (packed) {
+      const size_t entries = L.idx.size();
+      std::vector<fem::uint> rec(3 * entries, 0u);
+      std::vector<float> scale(op.V, 0.0f);
+      constexpr int kQ = (1 << 20) - 1;
+      std::vector<unsigned char> bad(L.nslices, 0);
+      fem::parallelFor(L.nslices, 256, [&](size_t s0, size_t s1) {
+        for (size_t sl = s0; sl < s1; sl++) {
+          const size_t off = L.slice_off[sl], width = (L.slice_off[sl + 1] - off) / 64;
+          for (size_t lane = 0; lane < 64; lane++) {
+            double big = 0;
+            for (size_t k = 0; k < width; k++)
+              for (int d = 1; d < 4; d++) big = std::max(big, std::fabs(L.coef[4 * (off + 64 * k + lane) + d]));
+            if (!std::isfinite(big)) bad[sl] = 1;
+            const float sc = std::isfinite(big) ? (float)(big / kQ) : 0.0f;
+            const size_t v = 64 * sl + lane;
+            if (v < op.V) scale[v] = sc;
+            for (size_t k = 0; k < width; k++) {
+              const size_t e = off + 64 * k + lane;
+              const float wt = (float)L.coef[4 * e];
+              fem::uint q[3] = {0, 0, 0};
+              for (int d = 0; d < 3; d++) {
+                long x = sc > 0 ? std::lrint(L.coef[4 * e + 1 + d] / (double)sc) : 0;
+                x = std::max<long>(-kQ, std::min<long>(kQ, x));
+                q[d] = (fem::uint)x & 0x1fffffu;
+              }
+              memcpy(&rec[3 * e], &wt, 4);
+              rec[3 * e + 1] = q[0] | (q[1] << 21);
+              rec[3 * e + 2] = (q[1] >> 11) | (q[2] << 10);
+            }
+          }
+        }
+      });
+      for (unsigned char b : bad) if (b) packed = false;      // a coefficient that is not finite: keep four floats, NaN and all
+      if (packed) {
+        ok(hipMalloc(&p->coef, 4 * rec.size())) && ok(hipMemcpy(p->coef, rec.data(), 4 * rec.size(), hipMemcpyHostToDevice)) &&
+        ok(hipMalloc((void **)&p->rscale, 4 * scale.size())) && ok(hipMemcpy(p->rscale, scale.data(), 4 * scale.size(), hipMemcpyHostToDevice));
+        p->packed = true;
+      }
+    }
+    if (!packed) uploadCoef(&p->coef, L.coef);
   }
   ok(hipMalloc(&p->state[0], 2 * sb * p->V)) && ok(hipMalloc(&p->state[1], 2 * sb * p->V));
   if (e == hipSuccess && (flags & FEM_PLAN_DEVICE_ASSEMBLY)) {
@@ -887,14 +933,18 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
   for (int i = 0; i < nsteps; i++) {
     void *src = p->state[p->cur], *dst = p->state[p->cur ^ 1];
     const bool nt = p->sell_nt >= 0 ? p->sell_nt != 0 : fem_plan_operator_bytes(p) > (256ull << 20);   // see launchTile
-    if (p->precision == FEM_PREC_F32)
+    if (p->precision == FEM_PREC_F32 && p->packed)
+      hipLaunchKernelGGL((nt ? sell_step_kernel<float, true, false, true> : sell_step_kernel<float, false, false, true>), dim3(p->nblocks), dim3(256), 0,
+                         (hipStream_t)stream, (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
+                         p->V, p->nslices, p->nblocks, mf, (const float *)p->rscale);
+    else if (p->precision == FEM_PREC_F32)
       hipLaunchKernelGGL((nt ? sell_step_kernel<float, true> : sell_step_kernel<float, false>), dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const float2 *)src, (float2 *)dst, p->slice_off.p, p->idx.p, (const float4 *)p->coef,
-                         p->V, p->nslices, p->nblocks, mf);
+                         p->V, p->nslices, p->nblocks, mf, (const float *)nullptr);
     else
       hipLaunchKernelGGL((nt ? sell_step_kernel<double, true> : sell_step_kernel<double, false>), dim3(p->nblocks), dim3(256), 0, (hipStream_t)stream,
                          (const double2 *)src, (double2 *)dst, p->slice_off.p, p->idx.p, (const double4 *)p->coef,
-                         p->V, p->nslices, p->nblocks, md);
+                         p->V, p->nslices, p->nblocks, md, (const float *)nullptr);
     p->cur ^= 1;
   }
   HIP_TRY(hipGetLastError());
@@ -1036,6 +1086,26 @@ int fem_plan_download_coef(fem_plan *p, double *out) {
   if (!p || !out) return fail(FEM_ERR_INVALID, "fem_plan_download_coef: null");
   const void *dev = p->ksteps > 0 ? p->tcoef : p->coef;
   const size_t n = fem_plan_coef_count(p);
+  if (p->packed && p->ksteps == 0) {   // sliced ELL: records at 3 * e words, scales per row
+    const size_t entries = n / 4;
+    std::vector<fem_uint> rec(3 * entries), soff(p->nslices + 1);
+    std::vector<float> scale(p->V);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(rec.data(), dev, 4 * rec.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(scale.data(), p->rscale, 4 * scale.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(soff.data(), p->slice_off.p, 4 * soff.size(), hipMemcpyDeviceToHost));
+    for (size_t sl = 0; sl < p->nslices; sl++)
+      for (size_t e = soff[sl]; e < soff[sl + 1]; e++) {
+        const size_t v = std::min<size_t>(64 * sl + (e - soff[sl]) % 64, p->V - 1);
+        const fem_uint a = rec[3 * e + 1], b = rec[3 * e + 2];
+        float wt;
+        memcpy(&wt, &rec[3 * e], 4);
+        const float sc = scale[v];
+        const int qx = (int)(a << 11) >> 11, qy = (int)(((a >> 21) | (b << 11)) << 11) >> 11, qz = (int)(b << 1) >> 11;
+        out[4 * e] = wt; out[4 * e + 1] = (float)qx * sc; out[4 * e + 2] = (float)qy * sc; out[4 * e + 3] = (float)qz * sc;
+      }
+    return FEM_OK;
+  }
   if (p->packed) {                     // 12-byte records: decoded the way the kernel decodes them
     std::vector<float> c32(n);
     std::vector<fem_uint> meta(16 * (size_t)p->ntiles);
@@ -1179,6 +1249,7 @@ uint64_t fem_plan_operator_bytes(const fem_plan *p) {
   if (!p) return 0;
   const size_t sb = p->precision == FEM_PREC_F32 ? 4 : 8;
   if (p->ksteps > 0) return p->tile_bytes;
+  if (p->packed) return (uint64_t)p->entries * (4 + 12) + (uint64_t)p->V * 4 + (uint64_t)(p->nslices + 1) * 4;
   return (uint64_t)p->entries * (4 + 4 * sb) + (uint64_t)(p->nslices + 1) * 4;
 }
 

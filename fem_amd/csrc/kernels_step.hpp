@@ -140,11 +140,17 @@ __global__ __launch_bounds__(256) void ref_step_kernel(
 // Algorithmic bytes per vertex (fp32, valence 6): 6*(4+16) operator + 8 state
 // read + 8 state write = 136 B (+ gathers served on chip).
 // ---------------------------------------------------------------------------
-template <typename T, bool NT, bool IMEX = false>
+// PK (fp32 plans whose operator comes from the host assembly): the operator stream in 12-byte records -- the weight
+// in fp32 and the three gradient coefficients as 21-bit integers against the row's scale, as in the fused kernel below
+// (there: the format and its accuracy) -- at 3 * e words of `coef`, with rscale[v] the scale of row v: 100 B per
+// vertex-step (valence 6) instead of 120 of operator.
+template <typename T, bool NT, bool IMEX = false, bool PK = false>
 __global__ __launch_bounds__(256) void sell_step_kernel(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ slice_off, const uint *__restrict__ idx,
-    const typename Vec<T>::t4 *__restrict__ coef, uint V, uint nslices, uint nblocks, ModelT<T> m) {
+    const typename Vec<T>::t4 *__restrict__ coef, uint V, uint nslices, uint nblocks, ModelT<T> m,
+    const float *__restrict__ rscale = nullptr) {
+  static_assert(!PK || sizeof(T) == 4, "packed operator records: fp32 plans");
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   // bijective XCD remap: blocks b, b+8, b+16, ... (one XCD) get consecutive slices
@@ -159,9 +165,22 @@ __global__ __launch_bounds__(256) void sell_step_kernel(
   const uint vs = v < V ? v : V - 1;
   const T2 s = src[vs];
   T lapn = 0, lapc = 0, gnx = 0, gny = 0, gnz = 0, gcx = 0, gcy = 0, gcz = 0;
+  float rs = 0;
+  if constexpr (PK) rs = NT ? __builtin_nontemporal_load(&rscale[vs]) : rscale[vs];
   auto entry = [&](uint e) {
     const uint j = NT ? __builtin_nontemporal_load(&idx[e]) : idx[e];     // read-once streams: do not evict the state
-    const T4 c = NT ? ntload(&coef[e]) : coef[e];
+    T4 c;
+    if constexpr (PK) {
+      const uint *rec = reinterpret_cast<const uint *>(coef) + 3 * (size_t)e;
+      const uint w0 = NT ? __builtin_nontemporal_load(rec) : rec[0], a = NT ? __builtin_nontemporal_load(rec + 1) : rec[1],
+                 b2 = NT ? __builtin_nontemporal_load(rec + 2) : rec[2];
+      c.x = __uint_as_float(w0);
+      c.y = (T)((float)((int)(a << 11) >> 11) * rs);
+      c.z = (T)((float)((int)(__builtin_amdgcn_alignbit(b2, a, 21) << 11) >> 11) * rs);
+      c.w = (T)((float)((int)(b2 << 1) >> 11) * rs);
+    } else {
+      c = NT ? ntload(&coef[e]) : coef[e];
+    }
     const T2 f = src[j];
     const T dn = f.x - s.x, dc = f.y - s.y;
     lapn += c.x * dn; lapc += c.x * dc;

@@ -367,7 +367,8 @@ uint64_t fem_plan_operator_bytes(const fem_plan *p);
  * 0 = four scalars of the plan's precision (w, Cx, Cy, Cz);
  * 1 = 12-byte records: w in fp32 and Cx, Cy, Cz as 21-bit signed integers against a per-row fp32 scale (rounding
  *     error at most 4.8e-7 of the row's largest gradient coefficient; the entries beyond the sixth of a wider row
- *     stay four floats).  Default for fused fp32 plans whose operator comes from the host assembly;
+ *     stay four floats).  Default for fp32 plans, fused or single-step, whose operator comes from the host assembly
+ *     and that are not FEM_PLAN_IMPLICIT;
  *     FEM_TILE_PACKED=0 in the environment at plan creation keeps format 0.  fem_plan_download_coef returns the
  *     decoded values either way. */
 int fem_plan_operator_format(const fem_plan *p);

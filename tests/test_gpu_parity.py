@@ -534,7 +534,23 @@ def test_packed_operator_records(cfg, ksteps, monkeypatch):
     # observed: packed vs fp32 records 2e-9, either against the oracle 2.4e-9 (1M vertices, 25..3200 steps: 1e-9..3e-9
     # between the two, 1e-8..2e-7 against the oracle for both, equal to four digits: tests/report_packed_accuracy.py)
     assert rel_l2(out[0][0], out[1][0]) <= 1e-8 and e_packed <= 2 * e_plain + 1e-9, (e_packed, e_plain, rel_l2(out[0][0], out[1][0]))
+    # the single-step (sliced-ELL) plan reads the same records
+    sell = fa.Plan(case.mesh, fa.PREC_F32)
+    monkeypatch.setenv("FEM_TILE_PACKED", "0")
+    sell_plain = fa.Plan(case.mesh, fa.PREC_F32)
+    monkeypatch.delenv("FEM_TILE_PACKED")
+    assert sell.operator_format() == 1 and sell_plain.operator_format() == 0 and sell.operator_bytes() < 0.86 * sell_plain.operator_bytes()
+    a, b = sell.coef(), sell_plain.coef()
+    assert a.shape == b.shape and np.array_equal(a[:, 0], b[:, 0]) and 0 < np.abs(a[:, 1:] - b[:, 1:]).max() <= big * 2.0 ** -21 * 1.01
+    res = []
+    for plan in (sell, sell_plain):
+        plan.set_state(n0, c0)
+        plan.run(steps, case.dt, case.model)
+        res.append(plan.get_state())
+    assert rel_l2(res[0][0], n_ref) <= TOL_F32 and rel_l2(res[0][1], c_ref) <= TOL_F32
+    assert rel_l2(res[0][0], res[1][0]) <= 1e-8 and rel_l2(res[0][0], n_ref) <= 2 * rel_l2(res[1][0], n_ref) + 1e-9
     # plans that keep four scalars per entry
+    assert fa.Plan(case.mesh, fa.PREC_F32, implicit=True).operator_format() == 0
     assert fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps).operator_format() == 0
     assert fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps, assemble=True).operator_format() == 0
     # rows wider than the register tile's six entries: their first six entries in records, the rest four floats
