@@ -1,21 +1,26 @@
 """Accuracy of the 12-byte operator records (FEM_TILE_PACKED) against the fp32 records and the f64 oracle:
 rel-L2 of n after a number of steps, from the linear regime into the developed pattern.
-usage (GPU box): PYTHONPATH=. python tests/report_packed_accuracy.py [nu] [steps ...]"""
+usage (GPU box): PYTHONPATH=. python tests/report_packed_accuracy.py [nu | scan:nu] [steps ...]
+(scan:nu = the irregular "scanned-like" mesh of config 4 with its stable time step and the 1536-row tile)"""
 import os, sys, json
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import fem_amd as fa
 import oracle_lib as ol
 
-nu = int(sys.argv[1]) if len(sys.argv) > 1 else 160
+scan = len(sys.argv) > 1 and sys.argv[1].startswith("scan:")
+nu = int(sys.argv[1].split(":")[-1]) if len(sys.argv) > 1 else 160
 checkpoints = [int(a) for a in sys.argv[2:]] or [25, 100, 400, 1600]
-pts, tri = fa.make_icosphere(nu, 0.1)
+pts, tri = fa.make_scanned_like(nu, 0.1, seed=3) if scan else fa.make_icosphere(nu, 0.1)
 mesh = fa.Mesh(pts, tri)
-part = mesh.partition(max(1, mesh.V // 975))
+part = mesh.partition(max(1, mesh.V // (820 if scan else 975)))
 om = part.ordered
 om.init_stats(fa.PREC_MIXED)
 dt = 0.1 * om.stats()["maxEdgeLen"] ** 2
 model = fa.default_model()
+if scan:
+    from fem_amd.dist import _time_step
+    dt = _time_step(om, model, "stable")
 n0, c0 = fa.initial_condition(om.V, 1)
 st = ol.Stats(ol.Topology(om.V, om.tri), om.points, ol.F64)
 ol.set_threads(16)
@@ -26,7 +31,7 @@ def rel(a, b):
 plans = {}
 for name, env in (("packed", "1"), ("fp32", "0")):
     os.environ["FEM_TILE_PACKED"] = env
-    plans[name] = fa.Plan(om, fa.PREC_F32, part=part, ksteps=7)
+    plans[name] = fa.Plan(om, fa.PREC_F32, part=part, ksteps=5 if scan else 7)
     plans[name].set_state(n0, c0)
 bn = model.nMax
 n_ref = bn + (n0 - bn).astype(np.float32).astype(np.float64)
