@@ -404,7 +404,9 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
         // of all coefficients: + 43 VGPRs)
         typedef T V2 __attribute__((ext_vector_type(2)));
         V2 an = {0, 0}, bn = {0, 0}, ac = {0, 0}, bc = {0, 0};       // (lap, gx), (gy, gz) of n and of c
-        if constexpr (IXL) {
+        // (the first row's offsets stay in registers where that costs no spill -- builds without the wide-row
+        //  staging: one LDS round trip less per step, +0.6 % in a same-box A/B; a second row's spill in the loop: -11 %)
+        if (IXL && q >= (X == 1 ? 1 : 0)) {
 #pragma unroll
           for (int w = 0; w < W / 2; w++) ix[q][w] = xs_ix[w * (TPB * R) + r];
         }
