@@ -9,12 +9,21 @@ steps, then back-to-back launches with no host sync inside, device-event timed).
                   [--fuse k] [--mesh FILE.off|.ply [--subdivide L]]
   python bench.py --workload deform4m [--unfused]      config 5: re-assembly on the device every step
 
+  python bench.py --gpus N ...        N > 1 from a bare shell: this process starts N fresh rank processes (one per GPU,
+                                      RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), relays rank 0's line and exits non-zero
+                                      if any rank does; it never touches the GPU itself.  Under torch.distributed.run
+                                      (WORLD_SIZE already set) the process is a rank.
+
 Prints ONE JSON line (rank 0).  See DESIGN.md "Measurement" for the byte accounting.
 """
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +48,78 @@ WORKLOADS = {                       # class-I geodesic spheres, edge ~ 0.1 (BASE
 ALG_BYTES_PER_ELEMENT_ASSEMBLY = 68  # 54 B per element + 14 B of per-vertex output
 ALG_BYTES_PER_VERTEX_STEP = 168     # V*24 + nnz*8 + F*48 on a closed genus-0 mesh
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def host_thread_share(local_world):
+    """host worker threads one rank may use when `local_world` ranks share this host: the cores this process may
+    run on, divided by the ranks, within [2, 16] (16 = the library's own default cap)"""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cores = os.cpu_count() or 1
+    return max(2, min(16, cores // max(1, local_world)))
+
+
+def launch_ranks(nranks, cmd, env=None, grace=10.0):
+    """One fresh process per rank, the way the reference's harness is one process that times itself
+    (src/main.cpp:547-575) and the driver's `python bench.py --gpus N` expects: `cmd` is started `nranks` times with
+    RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT (a free port) set.
+    Rank 0's stdout is relayed line by line to this process's stdout, the other ranks' stdout goes to stderr.
+    Returns 0 when every rank exited 0; as soon as one rank fails, the others (exact PIDs) get SIGTERM, then SIGKILL
+    after `grace` seconds, and the first non-zero status is returned.  The caller must not have touched the GPU:
+    nothing here does, and no process is replaced (no exec of an initialised process)."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("FEM_HOST_THREADS", str(host_thread_share(nranks)))
+    procs = []
+    for r in range(nranks):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr,
+                                      text=True, bufsize=1))
+
+    def relay(pipe):
+        for line in pipe:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, args=(procs[0].stdout,), daemon=True)
+    t.start()
+
+    def forward(signum, _frame):
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signum)
+    old = {sg: signal.signal(sg, forward) for sg in (signal.SIGTERM, signal.SIGINT)}
+    status = 0
+    try:
+        live = set(range(nranks))
+        while live:
+            for r in sorted(live):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                live.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 128 - rc
+                    print("bench.py: rank %d exited with status %d; stopping the other ranks" % (r, rc), file=sys.stderr)
+                    for q in live:
+                        procs[q].terminate()
+                    deadline = time.monotonic() + grace
+                    while any(procs[q].poll() is None for q in live) and time.monotonic() < deadline:
+                        time.sleep(0.05)
+                    for q in live:
+                        if procs[q].poll() is None:
+                            procs[q].kill()
+            time.sleep(0.02)
+        for p in procs:
+            p.wait()
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    t.join(timeout=5.0)
+    return status
 
 
 def cpu_baseline(seconds_budget=12.0):
@@ -134,40 +215,84 @@ def verify_deform(runner, state, total_steps):
                       % ("mixed" if f32 else "f64", threads, time.perf_counter() - t0)}
 
 
-def verify_against_oracle(runner, state, total_steps, seed=1):
-    """The check the reference's caller makes after its warm-up steps (GPUrun, main.cpp:492-541: the CPU path run
-    for the same step count, then per-vertex differences) -- outside the timed region: the oracle's all-f64 CPUrun
-    restatement (OpenMP) from the same initial condition on the same ordered mesh for warmup+steps time steps,
-    compared with the state the timed kernel left (downloaded right after the timed region)."""
+def _rounded_ic(runner, V, precision):
+    """the initial condition as the plan holds it: fp32 plans store fp32 deviations from the homogeneous state
+    (fem_plan_set_state), so the oracle starts from those values"""
     import numpy as np
     import fem_amd as fa
+    n0, c0 = fa.initial_condition(V, runner.seed)
+    if precision == "f32":
+        bn, bc = runner.model.nMax, runner.model.nMax / (1.0 + runner.model.nMax)
+        n0 = bn + (n0 - bn).astype(np.float32).astype(np.float64)
+        c0 = bc + (c0 - bc).astype(np.float32).astype(np.float64)
+    return n0, c0
+
+
+def oracle_reference(runner, total_steps, precision):
+    """The check the reference's caller makes after its warm-up steps (GPUrun, main.cpp:492-541: the CPU path run
+    for the same step count, then per-vertex differences) -- outside the timed region: the oracle's all-f64 CPUrun
+    restatement (OpenMP) from the same initial condition on the same ordered mesh for `total_steps` time steps."""
     import oracle_lib as ol
     t0 = time.perf_counter()
     om = runner.part.ordered
     topo = ol.Topology(om.V, om.tri)
     st = ol.Stats(topo, om.points, ol.F64)
-    n0, c0 = fa.initial_condition(om.V, seed)
-    if runner.precision == "f32":        # the fp32 plan starts from the fp32-rounded deviations (fem_plan_set_state)
-        bn, bc = runner.model.nMax, runner.model.nMax / (1.0 + runner.model.nMax)
-        n0 = bn + (n0 - bn).astype(np.float32).astype(np.float64)
-        c0 = bc + (c0 - bc).astype(np.float32).astype(np.float64)
+    n0, c0 = _rounded_ic(runner, om.V, precision)
     threads = ol.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1))
     n_ref, c_ref = st.step(n0, c0, runner.dt, total_steps, runner.model.as_array())
     ol.set_threads(1)
-    n, c = state
-
-    def rel(a, b):
-        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
-    # the departure from the homogeneous state is what the steps compute: report the error relative to it too
-    dev = max(float(np.linalg.norm(n_ref - runner.model.nMax)), 1e-300)
-    return {"rel_l2_n": rel(n, n_ref), "rel_l2_c": rel(c, c_ref), "rel_l2_n_deviation": float(np.linalg.norm(n - n_ref) / dev),
-            "max_abs_n": float(np.abs(n - n_ref).max()), "steps": total_steps, "tolerance": 1e-5 if runner.precision == "f32" else 1e-11,
-            "state_changed": bool(np.abs(n - n0).max() > 0),      # the device state left the initial condition: the kernel ran
+    return {"n": n_ref, "c": c_ref, "n0": n0, "steps": total_steps, "ic_precision": precision,
             "oracle": "fo_step_f64 (oracle/, %d threads), same IC and ordered mesh, %.1f s" % (threads, time.perf_counter() - t0)}
 
 
+# fp32 / fp64 bars: relative L2 of the fields themselves (the north star's wording, <= 1e-5 fp32) AND relative to the
+# DEVIATION from the homogeneous state, which is what the steps compute (||n - nMax|| ~ 0.003 ||n||): a 0.3 % error of
+# the pattern would pass the first bar alone
+TOL = {"f32": (1e-5, 1e-5), "f64": (1e-11, 1e-9)}
+
+
+def compare_with_oracle(ref, state, model, precision):
+    """`state` = (n, c) of the whole ordered mesh as the device left it after ref["steps"] steps"""
+    import numpy as np
+    n, c = state
+    n_ref, c_ref = ref["n"], ref["c"]
+    bn, bc = model.nMax, model.nMax / (1.0 + model.nMax)
+
+    def rel(a, b):
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+    tol, tol_dev = TOL[precision]
+    v = {"rel_l2_n": rel(n, n_ref), "rel_l2_c": rel(c, c_ref),
+         "rel_l2_n_deviation": float(np.linalg.norm(n - n_ref) / max(float(np.linalg.norm(n_ref - bn)), 1e-300)),
+         "rel_l2_c_deviation": float(np.linalg.norm(c - c_ref) / max(float(np.linalg.norm(c_ref - bc)), 1e-300)),
+         "max_abs_n": float(np.abs(n - n_ref).max()), "steps": ref["steps"], "tolerance": tol, "tolerance_deviation": tol_dev,
+         "state_changed": bool(np.abs(n - ref["n0"]).max() > 0),   # the device state left the initial condition: the kernel ran
+         "oracle": ref["oracle"]}
+    v["ok"] = bool(max(v["rel_l2_n"], v["rel_l2_c"]) <= tol and
+                   max(v["rel_l2_n_deviation"], v["rel_l2_c_deviation"]) <= tol_dev and v["state_changed"])
+    return v
+
+
+def gather_owned(runner, world, rank, group):
+    """N > 1: the owned rows of every rank on rank 0 (over the gloo control group when there is one), as whole-mesh
+    arrays in the ordered numbering; None on the other ranks"""
+    import numpy as np
+    import torch.distributed as dist
+    n, c = runner.get_owned()
+    got = [None] * world if rank == 0 else None
+    dist.gather_object((int(runner.shard.own_begin), int(runner.shard.own_end), n, c), got, dst=0, group=group)
+    if rank != 0:
+        return None
+    V = runner.part.ordered.V
+    fn, fc, covered = np.full(V, np.nan), np.full(V, np.nan), 0
+    for b, e, rn, rc in got:
+        fn[b:e], fc[b:e] = rn, rc
+        covered += e - b
+    if covered != V:
+        raise SystemExit("bench.py: the ranks' owned ranges cover %d of %d vertices" % (covered, V))
+    return fn, fc
+
+
 def main():
-    verify_failed = False
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -181,23 +306,39 @@ def main():
                          "else the measured best: 7 on the spheres, 5 on the irregular scanned-like meshes")
     ap.add_argument("--unfused", action="store_true", help="deform workloads: assembly kernel, then step kernel (two kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the timed run's result (N=1, warmup+steps <= 64)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the run's result")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N=1 fp32 fused runs: skip config.variants (the same mesh on the fp64 plan and on four-float records)")
+    ap.add_argument("--verify-steps", type=int, default=25,
+                    help="runs longer than 64 steps: this many steps are taken and checked against the oracle BEFORE the "
+                         "timed region on the same plan (the state is reset afterwards)")
     ap.add_argument("--sustained-steps", type=int, default=1000,
-                    help="N=1: the same kernel timed over this many further steps after the timed region (config.sustained); 0 = off")
+                    help="the same kernel timed over this many further steps after the timed region (config.sustained); 0 = off")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = rehearsal only (ranks may share a GPU; halo staged through the host)")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-
-    import fem_amd as fa
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: this process becomes the launcher and never touches the GPU
+        raise SystemExit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1 and "FEM_HOST_THREADS" not in os.environ:
+        # every rank reads, builds the topology of and partitions the same mesh (deterministic, so no broadcast is
+        # needed): the ranks of one host share its cores instead of each taking the single-process default of 16
+        os.environ["FEM_HOST_THREADS"] = str(host_thread_share(int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import fem_amd as fa
+    from fem_amd import dist as fdist
+
     share = args.dist_backend == "gloo" or os.environ.get("FEM_BENCH_SHARE_GPU") == "1"   # rehearsals only
     local_dev = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(local_dev)
@@ -216,12 +357,23 @@ def main():
             dist.init_process_group("gloo")
 
     def rank_barrier():
-        if control is not None and getattr(runner, "host_group", None) is not None:
+        if world == 1:
+            return
+        if control is not None:
             dist.all_reduce(torch.zeros(1), group=control)
         elif args.dist_backend == "nccl":
             dist.barrier(device_ids=[local_dev])
         else:
             dist.barrier()
+
+    def max_over_ranks(values):
+        if world == 1:
+            return values
+        staged = control if control is not None else None
+        t = torch.tensor(values, dtype=torch.float64,
+                         device="cuda" if args.dist_backend == "nccl" and staged is None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=staged)
+        return [float(x) for x in t]
 
     wl = WORKLOADS[args.workload] if args.mesh is None else dict(nu=0, verts_per_part=256, scanned=True)
     if args.fuse is None:
@@ -250,19 +402,15 @@ def main():
     if deform:
         if world > 1:
             raise SystemExit("bench.py: the deforming-mesh workloads run on one GPU")
-        from fem_amd import dist as fdist
         args.fuse, nparts = 0, max(1, V_total // wl["verts_per_part"])
         runner = fdist.DeformRun(mesh, nparts, args.precision, fused=not args.unfused)
     elif world > 1:
-        from fem_amd import dist as fdist
         runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse, dt_rule=dt_rule,
                                   control_group=control)
     else:
-        from fem_amd import dist as fdist
         runner = fdist.SingleRun(mesh, nparts, args.precision, ksteps=args.fuse, dt_rule=dt_rule)
     mesh_report = None
     if scanned and rank == 0:           # config 4: valence histogram and partition imbalance
-        import numpy as np
         val = np.bincount(tri.ravel().astype(np.int64), minlength=V_total)
         sizes = np.diff(runner.part.node_parts.astype(np.int64))
         fsizes = np.diff(runner.part.element_parts.astype(np.int64))[:-1]
@@ -272,56 +420,108 @@ def main():
                        "cut_faces_fraction": float((runner.part.element_parts[-1] - runner.part.element_parts[-2]) / len(tri))}
     del pts, tri, mesh
     t_host = time.perf_counter() - t_host
+    staged_group = getattr(runner, "host_group", None)
+    gather_group = control if control is not None else None
 
     stream = torch.cuda.current_stream()
-    runner.run(args.warmup, stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        rank_barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(stream)
-    runner.run(args.steps, stream)
-    ev1.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        rank_barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    final_state, sustained, asm_ms = None, None, None
-    if world == 1:
-        if not args.no_verify and args.warmup + args.steps <= (32 if deform else 64):
-            final_state = runner.plan.get_state()              # what the timed kernel left; checked below, outside all timing
-        if args.sustained_steps > 0 and args.sustained_steps != args.steps:
-            torch.cuda.synchronize()
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            tw = time.perf_counter()
-            s0.record(stream)
-            runner.run(args.sustained_steps, stream)
-            s1.record(stream)
-            torch.cuda.synchronize()
-            tw = time.perf_counter() - tw
-            sustained = {"steps": args.sustained_steps, "value": 2.0 * V_total * args.sustained_steps / tw,
-                         "ms_per_step": tw * 1e3 / args.sustained_steps,
-                         "device_ms_per_step": s0.elapsed_time(s1) / args.sustained_steps}
-        if deform:
-            # the dominant kernel alone (no deformation kernel between the launches), device events on its stream
-            reps = max(10, min(200, args.steps))
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record(stream)
-            runner.run(reps, stream, deform=False)
-            a1.record(stream)
-            torch.cuda.synchronize()
-            asm_ms = a0.elapsed_time(a1) / reps
-    if world > 1:
-        staged = getattr(runner, "host_group", None)
-        tmax = torch.tensor([wall, dev_ms], dtype=torch.float64,
-                            device="cuda" if args.dist_backend == "nccl" and staged is None else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=staged)
-        wall, dev_ms = float(tmax[0]), float(tmax[1])
 
+    def whole_state(r):
+        """(n, c) of the whole ordered mesh on rank 0 (None elsewhere)"""
+        if world > 1:
+            return gather_owned(r, world, rank, gather_group)
+        return r.plan.get_state()
+
+    def timed(r, steps, warmup):
+        """`warmup` untimed steps, then `steps` steps between a barrier + synchronize on both sides (wall clock, the
+        MAX over the ranks) and between two events on the launch stream (device time)"""
+        r.run(warmup, stream)
+        torch.cuda.synchronize()
+        rank_barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        r.run(steps, stream)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        rank_barrier()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        return max_over_ranks([wall, e0.elapsed_time(e1)])
+
+    def sustained_of(r, steps):
+        wall, dev = timed(r, steps, 0)
+        return {"steps": steps, "value": 2.0 * V_total * steps / wall, "ms_per_step": wall * 1e3 / steps,
+                "device_ms_per_step": dev / steps}
+
+    # ---- the check (outside every timed region).  Runs of <= 64 steps: the state the TIMED kernel left is compared
+    # with the oracle after warmup + steps steps.  Longer runs: --verify-steps steps are taken on the same plan before
+    # the timed region, downloaded, and the state is reset to the initial condition.
+    total = args.warmup + args.steps
+    check_steps, checked_state, check_kind = 0, None, None
+    do_verify = not args.no_verify
+    if do_verify and total > (32 if deform else 64):
+        check_steps = min(args.verify_steps, 10) if deform else args.verify_steps
+        runner.run(check_steps, stream)
+        torch.cuda.synchronize()
+        checked_state = whole_state(runner)
+        runner.reset()
+        check_kind = "%d steps taken before the timed region on the same plan; state reset afterwards" % check_steps
+
+    wall, dev_ms = timed(runner, args.steps, args.warmup)
+    if do_verify and check_steps == 0:
+        check_steps = total
+        checked_state = whole_state(runner)              # what the timed kernel left
+        check_kind = "the state the timed region left (warmup + steps)"
+    sustained, asm_ms = None, None
+    if args.sustained_steps > 0 and args.sustained_steps != args.steps:
+        sustained = sustained_of(runner, args.sustained_steps)
+    if deform:
+        # the dominant kernel alone (no deformation kernel between the launches), device events on its stream
+        reps = max(10, min(200, args.steps))
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(stream)
+        runner.run(reps, stream, deform=False)
+        a1.record(stream)
+        torch.cuda.synchronize()
+        asm_ms = a0.elapsed_time(a1) / reps
+
+    # ---- the same mesh on the reference's arithmetic type (fp64, src/common.h:7-11) and on lossless four-float
+    # operator records, measured after the headline with the same protocol (N = 1, fused fp32 runs only)
+    variants, variant_states = None, {}
+    if (world == 1 and not deform and not args.no_variants and args.precision == "f32" and args.fuse > 0
+            and args.mesh is None):
+        variants = {}
+        n0r, c0r = _rounded_ic(runner, V_total, "f32")       # the headline's effective IC: one oracle run serves all
+        for name, prec, packed in (("f64", "f64", None), ("f32_four_float", "f32", "0")):
+            old = os.environ.get("FEM_TILE_PACKED")
+            if packed is not None:
+                os.environ["FEM_TILE_PACKED"] = packed
+            try:
+                vr = fdist.SingleRun(None, nparts, prec, ksteps=args.fuse, part=runner.part, dt=runner.dt)
+            finally:
+                if packed is not None:
+                    if old is None:
+                        del os.environ["FEM_TILE_PACKED"]
+                    else:
+                        os.environ["FEM_TILE_PACKED"] = old
+            vr.plan.set_state(n0r, c0r)
+            if do_verify and total > 64:
+                vr.run(check_steps, stream)
+                torch.cuda.synchronize()
+                variant_states[name] = (vr.plan.get_state(), prec)
+                vr.plan.set_state(n0r, c0r)
+            vw, vd = timed(vr, args.steps, args.warmup)
+            if do_verify and total <= 64:
+                variant_states[name] = (vr.plan.get_state(), prec)
+            ti = vr.plan.tile_info()
+            variants[name] = {"value": 2.0 * V_total * args.steps / vw, "ms_per_step": vw * 1e3 / args.steps,
+                              "dtype": prec, "operator_records": ti["operator_records"],
+                              "tile": "%dx%d k%d" % (ti["threads"], ti["rows_per_thread"], ti["ksteps"]),
+                              "sustained": sustained_of(vr, args.sustained_steps) if args.sustained_steps > 0 else None}
+            del vr
+
+    verify_failed = False
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         spl = getattr(runner, "steps_per_launch", 1)
@@ -349,10 +549,13 @@ def main():
                        "elements_per_s": n_faces * args.steps / wall if deform else None,
                        "assembly_elements_per_s": n_faces / (asm_ms * 1e-3) if deform else None,
                        "vertex_steps_per_s": V_total * args.steps / wall, "host_setup_s": t_host,
+                       "host_threads_per_rank": int(os.environ.get("FEM_HOST_THREADS", "0")) or None,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report, "sustained": sustained,
-                       "parallelism": "1 rank" if world == 1 else "%d ranks, partition ranges + halo exchange%s" % (
-                           world, "" if getattr(runner, "fallback_reason", None) is None else
+                       "variants": variants,
+                       "parallelism": "1 rank" if world == 1 else "%d ranks (%s), partition ranges + halo exchange%s" % (
+                           world, "RCCL" if args.dist_backend == "nccl" else "gloo rehearsal, halo staged through the host",
+                           "" if getattr(runner, "fallback_reason", None) is None else
                            " STAGED THROUGH THE HOST over gloo (RCCL did not come up: %s)" % runner.fallback_reason)},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -363,19 +566,30 @@ def main():
                          "alg_bytes_per_vertex_step": None if deform else ALG_BYTES_PER_VERTEX_STEP,
                          "alg_bytes_per_element": ALG_BYTES_PER_ELEMENT_ASSEMBLY if deform else None, "avg_launch_ms": kernel_ms,
                          "time_steps_per_launch": args.steps / launches,
+                         "vertices_per_launch": "rank 0's owned rows" if world > 1 else "all rows",
                          "layout_bytes_per_launch": runner.layout_bytes_per_launch},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_deform() if deform else cpu_baseline()
-        if final_state is not None:
-            v = out["verify"] = (verify_deform if deform else verify_against_oracle)(runner, final_state, args.warmup + args.steps)
-            v["ok"] = bool(max(v["rel_l2_n"], v["rel_l2_c"]) <= v["tolerance"] and v.get("state_changed", True))
-            verify_failed = not v["ok"]
+        if checked_state is not None:
+            if deform:
+                v = out["verify"] = verify_deform(runner, checked_state, check_steps)
+                v["ok"] = bool(max(v["rel_l2_n"], v["rel_l2_c"]) <= v["tolerance"])
+            else:
+                ref = oracle_reference(runner, check_steps, args.precision)
+                v = out["verify"] = compare_with_oracle(ref, checked_state, runner.model, args.precision)
+                for name, (st, prec) in variant_states.items():
+                    vv = variants[name]["verify"] = compare_with_oracle(ref, st, runner.model, prec)
+                    # the fp64 plan started from the fp32-rounded IC the oracle used: its own bars apply
+                    verify_failed = verify_failed or not vv["ok"]
+            v["checked"] = check_kind
+            verify_failed = verify_failed or not v["ok"]
         print(json.dumps(out), flush=True)
     if world > 1:
+        rank_barrier()                                      # rank 0's oracle check is done: tear down together
         dist.destroy_process_group()
     if verify_failed:
-        raise SystemExit("bench.py: the timed run's result differs from the oracle beyond the tolerance (see \"verify\")")
+        raise SystemExit("bench.py: the run's result differs from the oracle beyond the tolerance (see \"verify\")")
 
 
 if __name__ == "__main__":

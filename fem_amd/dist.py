@@ -28,14 +28,19 @@ def _time_step(om, model, rule):
 
 class SingleRun:
     """partition -> reorder -> assemble (host, once) -> native plan; seeded IC of main.cpp:178-186"""
-    def __init__(self, mesh, nparts, precision="f32", seed=1, ksteps=0, dt_rule="reference"):
+    def __init__(self, mesh, nparts, precision="f32", seed=1, ksteps=0, dt_rule="reference", part=None, dt=None):
+        """`part` (+ `dt`): a Partition whose ordered mesh already carries its f64 stats -- a second plan on the
+        same mesh (bench.py's precision/format variants) repeats neither the partition nor the assembly"""
         self.ksteps = ksteps
         self.kernel_name = "tile_step_kernel" if ksteps > 0 else "sell_step_kernel"
-        self.part = _partition(mesh, nparts)
+        self.part = part if part is not None else _partition(mesh, nparts)
         om = self.part.ordered
-        om.init_stats(fa.PREC_F64)
         self.model = fa.default_model()
-        self.dt = _time_step(om, self.model, dt_rule)
+        if part is None or dt is None:
+            om.init_stats(fa.PREC_F64)
+            dt = _time_step(om, self.model, dt_rule)
+        self.dt = dt
+        self.seed = seed
         self.precision = precision
         self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, part=self.part, ksteps=ksteps)
         n0, c0 = fa.initial_condition(om.V, seed)
@@ -48,6 +53,11 @@ class SingleRun:
 
     def run(self, nsteps, stream=None):
         self.plan.run(nsteps, self.dt, self.model, stream.cuda_stream if stream is not None else None)
+
+    def reset(self):
+        """back to the seeded initial condition (bench.py: after the steps taken for the oracle check)"""
+        n0, c0 = fa.initial_condition(self.V, self.seed)
+        self.plan.set_state(n0, c0)
 
     def traffic_key(self):
         """what a PMC pass is valid for: kernel, precision, rows, fused depth, register tile, partition count"""
@@ -105,6 +115,11 @@ class DeformRun:
                 self.plan.assemble(s)
                 self.plan.run(1, self.dt, self.model, s)
             self.iteration += 1
+
+    def reset(self):
+        n0, c0 = fa.initial_condition(self.V, self.seed)
+        self.plan.set_state(n0, c0)
+        self.iteration = 0
 
     def traffic_key(self):
         return "%s:%s:%d" % (self.kernel_name, self.precision, self.V)
@@ -279,7 +294,9 @@ class ShardedRun:
                     self.fallback_reason = ("%s: %s" % (type(err).__name__, str(err).strip().splitlines()[0][:160])
                                             if err is not None else "RCCL failed on another rank")
                     exchange_halo(self.stepper, self.shard, None, host_group=control_group)
-        self.vertices_per_launch = self.shard.n_local
+        # what a launch advances for the job: the rows this rank owns (ghost rows are redundant work, not output)
+        self.vertices_per_launch = self.shard.n_own
+        self.seed = seed
         sb = 4 if precision == "f32" else 8
         plan = self.plan
         self.layout_bytes_per_launch = (plan.operator_bytes() + 4 * sb * self.shard.n_local) if plan else None
@@ -400,6 +417,21 @@ class ShardedRun:
     def get_owned(self):
         self._wait_exchange()
         return self.stepper.get_owned()
+
+    def reset(self):
+        """back to the seeded initial condition on owned and ghost rows alike, ghost budget full again"""
+        if self.plan is None:
+            raise fa.FemError("ShardedRun.reset: only for plans on the device")
+        self._wait_exchange()
+        n0, c0 = fa.initial_condition(self.V, self.seed)
+        l2g = self.shard.loc2glob
+        self.plan.set_state(n0[l2g], c0[l2g])              # synchronises the device first
+        self.budget = self.krings
+
+    def traffic_key(self):
+        ti = self.plan.tile_info() if self.plan is not None else None
+        return "%s:%s:shard %d of %d" % (self.kernel_name, self.precision, self.shard.rank, self.shard.nranks) + (
+            ":k%d:%dx%d" % (ti["ksteps"], ti["threads"], ti["rows_per_thread"]) if ti else "")
 
     def measured_traffic(self):
         return None, None

@@ -8,7 +8,7 @@ import pytest
 
 import fem_amd as fa
 import oracle_lib as ol
-from helpers import Case, rel_l2, scan_case, sphere_case, strip_case
+from helpers import Case, parity, rel_l2, scan_case, sphere_case, strip_case
 
 pytestmark = pytest.mark.gpu
 
@@ -70,7 +70,7 @@ def test_steps_on_device_assembled_deformed_mesh(ksteps):
     plan.run(6, dt, case.model)
     n_gpu, c_gpu = plan.get_state()
     n_ref, c_ref = st.step(case.n0, case.c0, dt, 6, case.model.as_array())
-    assert rel_l2(n_gpu, n_ref) <= 1e-11 and rel_l2(c_gpu, c_ref) <= 1e-11
+    parity(n_gpu, c_gpu, n_ref, c_ref, 1e-11)
     # set_points: new base positions from the host (ordered numbering)
     plan.set_points(case.pts)
     plan.assemble()
@@ -175,7 +175,7 @@ def test_config5_iteration_loop_vs_oracle(make, nparts, prec):
     outs = {}
     for mode in ("sell", "tile", "fused", "fused+store"):
         (n, c), edges, plan = _config5_loop(case, prec, mode)
-        assert rel_l2(n, n_ref) <= tol and rel_l2(c, c_ref) <= tol, (mode, rel_l2(n, n_ref), rel_l2(c, c_ref))
+        parity(n, c, n_ref, c_ref, tol, what=str((mode, rel_l2(n, n_ref), rel_l2(c, c_ref))))
         assert np.abs(np.array(edges) - np.array(e_ref)).max() <= (1e-12 if prec == "f64" else 2e-5) * max(e_ref), mode
         outs[mode] = (n, c)
         if mode == "fused+store":          # the stored operator is the one of the last deformation: one more plain step on it
@@ -183,7 +183,7 @@ def test_config5_iteration_loop_vs_oracle(make, nparts, prec):
             st = ol.Stats(case.topo, deformed(case.pts, 0.03, 0.9, 0.35 * 5), ol.F64 if prec == "f64" else ol.MIXED)
             n2, c2 = st.step(n_ref, c_ref, case.dt_loop, 1, case.model.as_array())
             g = plan.get_state()
-            assert rel_l2(g[0], n2) <= tol and rel_l2(g[1], c2) <= tol
+            parity(g[0], g[1], n2, c2, tol)
     # fused and unfused apply the same coefficients in the same order (two kernels: the compiler may contract a
     # multiply-add differently, hence a few ulp, not bit for bit)
     for other in ("sell", "fused+store"):

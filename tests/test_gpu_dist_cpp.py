@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import fem_amd as fa
-from helpers import rel_l2
+from helpers import parity, rel_l2  # noqa: F401
 from test_sharded import launch
 
 pytestmark = pytest.mark.gpu
@@ -75,7 +75,7 @@ def test_rccl_world_of_one_cpp(sphere_off, reference, tmp_path, fuse, rings, ove
     part, (n_ref, c_ref) = reference
     n, c, out = run_ranks(sphere_off, tmp_path, 1, fuse, rings, "rccl", overlap)
     assert "RCCL" in out
-    assert rel_l2(n, n_ref) <= 1e-11 and rel_l2(c, c_ref) <= 1e-11
+    parity(n, c, n_ref, c_ref, 1e-11)
 
 
 @pytest.mark.parametrize("ranks,fuse,rings,overlap", [(2, 4, 8, None), (3, 4, 4, "split"), (3, 3, 7, None), (4, 0, 3, None),
@@ -87,7 +87,7 @@ def test_ranks_as_threads_on_one_gpu(sphere_off, reference, tmp_path, ranks, fus
     part, (n_ref, c_ref) = reference
     n, c, out = run_ranks(sphere_off, tmp_path, ranks, fuse, rings, "inproc", overlap)
     assert "Ranks: %d (in-process copies" % ranks in out
-    assert rel_l2(n, n_ref) <= 1e-11 and rel_l2(c, c_ref) <= 1e-11
+    parity(n, c, n_ref, c_ref, 1e-11)
 
 
 def test_python_driver_agrees_with_cpp_host(sphere_off, reference, tmp_path):
@@ -97,7 +97,7 @@ def test_python_driver_agrees_with_cpp_host(sphere_off, reference, tmp_path):
     res = launch(1, tmp_path, backend="hip", sphere=NU, nparts=NPARTS, krings=8, steps=2 + 2 * ITER, precision="f32",
                  fuse=4, pg="nccl")[0]
     # (the Python worker builds the sphere in memory, fem_run reads its rounded .off text: 1e-9 apart, not bit-equal)
-    assert rel_l2(res["n"], n_cpp) <= 1e-7 and rel_l2(res["c"], c_cpp) <= 1e-7
+    parity(res["n"], res["c"], n_cpp, c_cpp, 1e-7)
 
 
 @pytest.mark.parametrize("ranks,transport", [(1, "rccl"), (2, "inproc"), (4, "inproc")])
@@ -124,7 +124,7 @@ def test_sharded_semi_implicit_steps(sphere_off, tmp_path, ranks, transport):
     plan.run_imex(2 + 2 * iters, dt, fa.default_model(), cg)
     n_ref, c_ref = plan.get_state()
     assert V == om.V and not np.array_equal(n_ref, n0)
-    assert rel_l2(raw[:V], n_ref) <= 1e-10 and rel_l2(raw[V:], c_ref) <= 1e-10
+    parity(raw[:V], raw[V:], n_ref, c_ref, 1e-10)
 
 
 def test_failing_rank_does_not_hang_the_others(sphere_off, tmp_path):

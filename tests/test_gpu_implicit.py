@@ -9,7 +9,7 @@ import scipy.sparse.linalg as spla
 
 import fem_amd as fa
 import oracle_lib as ol
-from helpers import rel_l2, scan_case, smooth_ic, sphere_case, stable_dt, strip_case
+from helpers import parity, scan_case, smooth_ic, sphere_case, stable_dt, strip_case
 
 pytestmark = pytest.mark.gpu
 
@@ -50,13 +50,13 @@ def test_imex_matches_scipy(make, nparts, factor):
     plan.run_imex(5, dt, case.model, cg_iterations=60)
     n, c = plan.get_state()
     assert max(plan.imex_residual()) <= 1e-9
-    assert rel_l2(n, n_ref) <= 1e-9 and rel_l2(c, c_ref) <= 1e-9
+    parity(n, c, n_ref, c_ref, 1e-9)
     # fp32 plan, fewer iterations
     plan32 = fa.Plan(case.mesh, fa.PREC_F32, implicit=True)
     plan32.set_state(n0, c0)
     plan32.run_imex(5, dt, case.model, cg_iterations=25)
     n32, c32 = plan32.get_state()
-    assert rel_l2(n32, n_ref) <= 1e-5 and rel_l2(c32, c_ref) <= 1e-5
+    parity(n32, c32, n_ref, c_ref, 1e-5)
 
 
 def test_imex_is_stable_where_explicit_is_not():

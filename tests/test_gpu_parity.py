@@ -1,20 +1,26 @@
 """GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
 
 Bars:
-  * `step` / fem_step on the reference layout (fp64 state, fp32 gradient branch, LDS float
-    atomics as in the reference): rel-L2 <= 1e-8 against the oracle's mixed-precision CPUrun.
-    Not bit-exact by construction: the reference's own float-atomic scatter is order-dependent
-    (error per step ~ alpha*dt*|Gn.Gc|*2^-24, about 1e-10 absolute on these inputs).
+  * `step` / fem_step on the reference layout (fp64 state, fp32 gradient branch): rel-L2 <= 3e-8
+    (TOL_REF below says why not 1e-8) against the oracle's mixed-precision CPUrun.  Not bit-exact
+    by construction: the fp32 products of the gradient branch are contracted differently by
+    different compilers, and the reference's own float-atomic scatter is order-dependent (error
+    per step ~ alpha*dt*|Gn.Gc|*2^-24, about 1e-10 absolute on these inputs).  The reference holds
+    no fixture at this level, so this bar is pinned by this repository's oracle alone.
   * native plan, fp64: rel-L2 <= 1e-11 against the all-fp64 oracle (same arithmetic, folded).
   * native plan, fp32: rel-L2 <= 1e-5 against the all-fp64 oracle after 100 steps from a
     smooth initial condition (the tolerance BASELINE.json's north_star states).
+Every comparison is made twice (helpers.parity): relative to the fields, as the north star words it,
+and relative to the DEVIATION of the reference from the homogeneous state (||n - nMax|| ~ 0.003 ||n||
+here) -- fp32 and the drop-in step <= 1e-5 of it, fp64 <= 1e-9 -- so that an error of the pattern
+itself cannot hide behind the magnitude of n.
 """
 import numpy as np
 import pytest
 
 import fem_amd as fa
 import oracle_lib as ol
-from helpers import rel_l2, scan_case, smooth_ic, sphere_case, stable_dt, strip_case
+from helpers import parity, rel_l2, scan_case, smooth_ic, sphere_case, stable_dt, strip_case
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +51,7 @@ def test_reference_step_symbol(make, nparts):
     fa.step(a, "fn_two", "fn_one", case.dt)
     n_gpu, c_gpu = dev.get_state()          # fn_one is current again
     n_ref, c_ref = case.ostats(ol.MIXED).step(case.n0, case.c0, case.dt, 2, case.model.as_array())
-    assert rel_l2(n_gpu, n_ref) <= TOL_REF and rel_l2(c_gpu, c_ref) <= TOL_REF
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_REF)
     assert not np.array_equal(n_gpu, case.n0)
 
 
@@ -74,7 +80,7 @@ def test_reference_layout_run_vs_packed_oracle():
     fn = np.stack([case.n0, case.c0], axis=1)
     for _ in range(20):
         fn = ol.step_packed(olay, case.n, case.part.node_parts, case.model.as_array(), case.dt, fn)
-    assert rel_l2(n_gpu, fn[:, 0]) <= TOL_REF and rel_l2(c_gpu, fn[:, 1]) <= TOL_REF
+    parity(n_gpu, c_gpu, fn[:, 0], fn[:, 1], TOL_REF)
 
 
 def test_reference_step_custom_model_and_clamp():
@@ -94,7 +100,7 @@ def test_reference_step_custom_model_and_clamp():
     assert (n_ref == 0).sum() > 10
     assert (n_gpu >= 0).all() and (c_gpu >= 0).all()
     assert np.abs(n_gpu[n_ref == 0]).max() <= 1e-5 and np.abs(n_ref[n_gpu == 0]).max() <= 1e-5
-    assert rel_l2(n_gpu, n_ref) <= 1e-6 and rel_l2(c_gpu, c_ref) <= 1e-6
+    parity(n_gpu, c_gpu, n_ref, c_ref, 1e-6)
 
 
 @pytest.mark.parametrize("ksteps", [0, 3])
@@ -115,7 +121,7 @@ def test_native_plan_clamp_and_custom_model(ksteps):
     plan.run(2, dt, model)
     n, c = plan.get_state()
     assert np.array_equal(n == 0, n_ref == 0) and (n >= 0).all() and (c >= 0).all()
-    assert rel_l2(n, n_ref) <= TOL_F64 and rel_l2(c, c_ref) <= TOL_F64
+    parity(n, c, n_ref, c_ref, TOL_F64)
     # non-default nMax: the base state the deviations are taken from follows the model
     model.nMax = 1.7
     plan2 = fa.Plan(case.mesh, fa.PREC_F32, model, part=case.part, ksteps=ksteps)
@@ -125,7 +131,7 @@ def test_native_plan_clamp_and_custom_model(ksteps):
     n2, c2 = plan2.get_state()
     r2 = case.ostats(ol.F64).step(nb.astype(np.float32).astype(np.float64), cb.astype(np.float32).astype(np.float64), case.dt, 5,
                                   model.as_array())
-    assert rel_l2(n2, r2[0]) <= TOL_F32 and rel_l2(c2, r2[1]) <= TOL_F32
+    parity(n2, c2, r2[0], r2[1], TOL_F32, nMax=1.7)
 
 
 def test_reference_step_limits_and_errors():
@@ -155,7 +161,7 @@ def test_native_plan_f64(make, nparts, steps):
     plan.run(steps, case.dt, case.model)
     n_gpu, c_gpu = plan.get_state()
     n_ref, c_ref = case.ostats(ol.F64).step(case.n0, case.c0, case.dt, steps, case.model.as_array())
-    assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F64)
 
 
 @pytest.mark.parametrize("make,nparts", [(lambda n: sphere_case(32, n), 52), (lambda n: strip_case(n), 3)])
@@ -171,7 +177,7 @@ def test_native_plan_f32_100_steps(make, nparts):
     # the fp32 path starts from the fp32-rounded state; give the oracle the same start
     n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
     n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
-    assert rel_l2(n_gpu, n_ref) <= TOL_F32 and rel_l2(c_gpu, c_ref) <= TOL_F32
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32)
 
 
 def test_native_plan_f32_random_ic_and_mixed_oracle():
@@ -186,7 +192,7 @@ def test_native_plan_f32_random_ic_and_mixed_oracle():
     n0r, c0r = case.n0.astype(np.float32).astype(np.float64), case.c0.astype(np.float32).astype(np.float64)
     for prec in (ol.F64, ol.MIXED):
         n_ref, c_ref = case.ostats(prec).step(n0r, c0r, case.dt, 100, case.model.as_array())
-        assert rel_l2(n_gpu, n_ref) <= TOL_F32 and rel_l2(c_gpu, c_ref) <= TOL_F32
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32)
 
 
 def test_native_plan_ragged_sizes():
@@ -201,7 +207,7 @@ def test_native_plan_ragged_sizes():
         plan.run(5, case.dt, case.model)
         n_gpu, c_gpu = plan.get_state()
         n_ref, c_ref = case.ostats(ol.F64).step(case.n0, case.c0, case.dt, 5, case.model.as_array())
-        assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F64)
 
 
 @pytest.mark.parametrize("ksteps", [0, 4])
@@ -243,7 +249,7 @@ def test_native_plan_full_size_properties(ksteps):
     plan64.set_state(n0.astype(np.float32), c0.astype(np.float32))
     plan64.run(20, dt, model)
     n64, c64 = plan64.get_state()
-    assert rel_l2(outs[0][0], n64) <= TOL_F32 and rel_l2(outs[0][1], c64) <= TOL_F32
+    parity(outs[0][0], outs[0][1], n64, c64, TOL_F32)
     # (iv)
     rgba, rgb, lo, hi = plan.format()
     n = outs[0][0]
@@ -267,7 +273,7 @@ def test_fused_tile_plan_f64(make, nparts, ksteps, steps):
     plan.run(steps, case.dt, case.model)
     n_gpu, c_gpu = plan.get_state()
     n_ref, c_ref = case.ostats(ol.F64).step(case.n0, case.c0, case.dt, steps, case.model.as_array())
-    assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F64)
 
 
 @pytest.mark.parametrize("cfg", [0, 2, 6, 7, 8])
@@ -290,7 +296,7 @@ def test_every_register_tile_geometry(cfg, prec, monkeypatch):
         n_gpu, c_gpu = plan.get_state()
         n_ref, c_ref = st.step(n0, c0, dt, steps, case.model.as_array())
         tol = TOL_F64 if prec == "f64" else 1e-5
-        assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol
+        parity(n_gpu, c_gpu, n_ref, c_ref, tol)
 
 
 def test_fused_tile_plan_f32_matches_single_step_plan():
@@ -305,10 +311,10 @@ def test_fused_tile_plan_f32_matches_single_step_plan():
         plan.set_state(n0, c0)
         plan.run(100, case.dt, case.model)
         outs.append(plan.get_state())
-    assert rel_l2(outs[0][0], outs[1][0]) <= 1e-6 and rel_l2(outs[0][1], outs[1][1]) <= 1e-6
+    parity(outs[0][0], outs[0][1], outs[1][0], outs[1][1], 1e-6)
     n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
     n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
-    assert rel_l2(outs[0][0], n_ref) <= TOL_F32 and rel_l2(outs[0][1], c_ref) <= TOL_F32
+    parity(outs[0][0], outs[0][1], n_ref, c_ref, TOL_F32)
 
 
 def test_irregular_mesh_all_paths():
@@ -329,7 +335,7 @@ def test_irregular_mesh_all_paths():
     dev.run(10, dt, case.model)
     n_gpu, c_gpu = dev.get_state()
     n_ref, c_ref = case.ostats(ol.MIXED).step(n0, c0, dt, 10, marr)
-    assert rel_l2(n_gpu, n_ref) <= TOL_REF and rel_l2(c_gpu, c_ref) <= TOL_REF
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_REF)
     # native plans, fp64
     case.mesh.init_stats(fa.PREC_F64)
     n_ref, c_ref = st.step(n0, c0, dt, 22, marr)
@@ -339,7 +345,7 @@ def test_irregular_mesh_all_paths():
         plan.set_state(n0, c0)
         plan.run(22, dt, case.model)
         outs[ksteps] = plan.get_state()
-        assert rel_l2(outs[ksteps][0], n_ref) <= TOL_F64 and rel_l2(outs[ksteps][1], c_ref) <= TOL_F64
+        parity(outs[ksteps][0], outs[ksteps][1], n_ref, c_ref, TOL_F64)
     # same accumulation order in both kernels: bit-identical results
     assert np.array_equal(outs[0][0], outs[4][0]) and np.array_equal(outs[0][1], outs[4][1])
     # fp32
@@ -350,7 +356,7 @@ def test_irregular_mesh_all_paths():
         plan.set_state(n0, c0)
         plan.run(100, dt, case.model)
         n_gpu, c_gpu = plan.get_state()
-        assert rel_l2(n_gpu, n_ref) <= TOL_F32 and rel_l2(c_gpu, c_ref) <= TOL_F32
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32)
 
 
 def test_irregular_mesh_small_tiles_and_sharded_plan():
@@ -367,7 +373,7 @@ def test_irregular_mesh_small_tiles_and_sharded_plan():
     plan.set_state(case.n0, case.c0)
     plan.run(9, dt, case.model)
     n_gpu, c_gpu = plan.get_state()
-    assert rel_l2(n_gpu, n_ref) <= TOL_F64 and rel_l2(c_gpu, c_ref) <= TOL_F64
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F64)
     # shard 1 of 3 with 3 ghost rings: 3 steps without exchange are exact on the owned rows
     shard = fa.Shard(case.part, 1, 3, 3)
     l2g = shard.loc2glob
@@ -378,7 +384,7 @@ def test_irregular_mesh_small_tiles_and_sharded_plan():
         sp.run(3, dt, case.model)
         ns, cs = sp.get_state()
         own = slice(0, shard.n_own)
-        assert rel_l2(ns[own], n3[l2g[own]]) <= TOL_F64 and rel_l2(cs[own], c3[l2g[own]]) <= TOL_F64
+        parity(ns[own], cs[own], n3[l2g[own]], c3[l2g[own]], TOL_F64)
 
 
 def test_config3_full_size_properties():
@@ -415,7 +421,7 @@ def test_config3_full_size_properties():
     single.set_state(n0, c0)
     single.run(12, dt, model)
     s = single.get_state()
-    assert rel_l2(a[0], s[0]) <= 1e-6 and rel_l2(a[1], s[1]) <= 1e-6
+    parity(a[0], a[1], s[0], s[1], 1e-6)
     assert np.isfinite(s[0]).all() and s[0].min() >= 0 and s[1].min() >= 0
     del single
     # and both are within the stated fp32 tolerance of the all-fp64 plan at this size
@@ -423,7 +429,7 @@ def test_config3_full_size_properties():
     p64.set_state(n0.astype(np.float32), c0.astype(np.float32))
     p64.run(12, dt, model)
     d = p64.get_state()
-    assert rel_l2(a[0], d[0]) <= TOL_F32 and rel_l2(a[1], d[1]) <= TOL_F32
+    parity(a[0], a[1], d[0], d[1], TOL_F32)
 
 
 def test_edge_cases_isolated_vertices_and_tiny_meshes():
@@ -450,13 +456,13 @@ def test_edge_cases_isolated_vertices_and_tiny_meshes():
             plan.set_state(case.n0, case.c0)
             plan.run(6, dt, case.model)
             n, c = plan.get_state()
-            assert rel_l2(n, n_ref) <= TOL_F64 and rel_l2(c, c_ref) <= TOL_F64, (len(p), ksteps)
+            parity(n, c, n_ref, c_ref, TOL_F64, what=str((len(p), ksteps)))
         lay, dev = _ref_device(case)
         dev.set_state(case.n0, case.c0)
         dev.run(6, dt, case.model)
         n, c = dev.get_state()
         n_m, c_m = case.ostats(ol.MIXED).step(case.n0, case.c0, dt, 6, marr)
-        assert rel_l2(n, n_m) <= TOL_REF and rel_l2(c, c_m) <= TOL_REF, len(p)
+        parity(n, c, n_m, c_m, TOL_REF, what=str(len(p)))
 
 
 # partition sizes bench.py pairs with each fused depth (rows per partition), by register tile
@@ -494,7 +500,7 @@ def test_timed_configuration_vs_oracle(cfg, ksteps, prec, monkeypatch):
         n_gpu, c_gpu = plan.get_state()
         n_ref, c_ref = st.step(n0, c0, dt, steps, case.model.as_array())
         tol = TOL_F64 if prec == "f64" else TOL_F32
-        assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol, (regular, rel_l2(n_gpu, n_ref), rel_l2(c_gpu, c_ref))
+        parity(n_gpu, c_gpu, n_ref, c_ref, tol, what=str((regular, rel_l2(n_gpu, n_ref), rel_l2(c_gpu, c_ref))))
         assert not np.array_equal(n_gpu, n0)
 
 
@@ -530,7 +536,7 @@ def test_packed_operator_records(cfg, ksteps, monkeypatch):
         out.append(plan.get_state())
     n_ref, c_ref = case.ostats(ol.F64).step(n0, c0, case.dt, steps, case.model.as_array())
     e_packed, e_plain = rel_l2(out[0][0], n_ref), rel_l2(out[1][0], n_ref)
-    assert e_packed <= TOL_F32 and rel_l2(out[0][1], c_ref) <= TOL_F32
+    parity(out[0][0], out[0][1], n_ref, c_ref, TOL_F32)
     # observed: packed vs fp32 records 2e-9, either against the oracle 2.4e-9 (1M vertices, 25..3200 steps: 1e-9..3e-9
     # between the two, 1e-8..2e-7 against the oracle for both, equal to four digits: tests/report_packed_accuracy.py)
     assert rel_l2(out[0][0], out[1][0]) <= 1e-8 and e_packed <= 2 * e_plain + 1e-9, (e_packed, e_plain, rel_l2(out[0][0], out[1][0]))
@@ -547,7 +553,7 @@ def test_packed_operator_records(cfg, ksteps, monkeypatch):
         plan.set_state(n0, c0)
         plan.run(steps, case.dt, case.model)
         res.append(plan.get_state())
-    assert rel_l2(res[0][0], n_ref) <= TOL_F32 and rel_l2(res[0][1], c_ref) <= TOL_F32
+    parity(res[0][0], res[0][1], n_ref, c_ref, TOL_F32)
     assert rel_l2(res[0][0], res[1][0]) <= 1e-8 and rel_l2(res[0][0], n_ref) <= 2 * rel_l2(res[1][0], n_ref) + 1e-9
     # plans that keep four scalars per entry
     assert fa.Plan(case.mesh, fa.PREC_F32, implicit=True).operator_format() == 0
@@ -574,7 +580,7 @@ def test_packed_operator_records(cfg, ksteps, monkeypatch):
         plan.run(33, dt, wide.model)
         res.append(plan.get_state())
     n_ref, c_ref = st.step(n0, c0, dt, 33, wide.model.as_array())
-    assert rel_l2(res[0][0], n_ref) <= TOL_F32 and rel_l2(res[0][1], c_ref) <= TOL_F32
+    parity(res[0][0], res[0][1], n_ref, c_ref, TOL_F32)
     assert rel_l2(res[0][0], res[1][0]) <= 1e-7, rel_l2(res[0][0], res[1][0])
 
 
@@ -599,7 +605,7 @@ def test_fused_plan_on_multilevel_partition(prec):
         plan.run(13, dt, case.model)
         n_gpu, c_gpu = plan.get_state()
         tol = TOL_F64 if prec == "f64" else TOL_F32
-        assert rel_l2(n_gpu, n_ref) <= tol and rel_l2(c_gpu, c_ref) <= tol
+        parity(n_gpu, c_gpu, n_ref, c_ref, tol)
     if prec == "f64":
         case = Case(*fa.make_icosphere(24, 0.1), 24, method="multilevel")
         lay, dev = _ref_device(case)
@@ -607,4 +613,4 @@ def test_fused_plan_on_multilevel_partition(prec):
         dev.run(4, case.dt, case.model)
         n_gpu, c_gpu = dev.get_state()
         n_ref, c_ref = case.ostats(ol.MIXED).step(case.n0, case.c0, case.dt, 4, case.model.as_array())
-        assert rel_l2(n_gpu, n_ref) <= TOL_REF and rel_l2(c_gpu, c_ref) <= TOL_REF
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_REF)

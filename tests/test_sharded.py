@@ -12,7 +12,7 @@ import pytest
 
 import fem_amd as fa
 import oracle_lib as ol
-from helpers import rel_l2
+from helpers import parity
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -54,7 +54,7 @@ def test_gloo_oracle_stepper(world, krings, steps, tmp_path):
     for r in res:
         b, e = int(r["own_begin"]), int(r["own_end"])
         assert not np.isnan(r["n"]).any() and not np.isnan(r["c"]).any()
-        assert rel_l2(r["n"], n_ref[b:e]) <= 1e-13 and rel_l2(r["c"], c_ref[b:e]) <= 1e-13
+        parity(r["n"], r["c"], n_ref[b:e], c_ref[b:e], 1e-13)
         covered += e - b
     assert covered == part.ordered.V
 
@@ -78,7 +78,7 @@ def test_gloo_overlapped_schedule_on_oracle_tiles(world, krings, fuse, steps, ov
     for r in res:
         b, e = int(r["own_begin"]), int(r["own_end"])
         assert not np.isnan(r["n"]).any() and not np.isnan(r["c"]).any()
-        assert rel_l2(r["n"], n_ref[b:e]) <= 1e-13 and rel_l2(r["c"], c_ref[b:e]) <= 1e-13
+        parity(r["n"], r["c"], n_ref[b:e], c_ref[b:e], 1e-13)
         if overlap == "0":
             assert tuple(r["classes"]) == (-1, -1, -1)
         else:
@@ -163,7 +163,7 @@ def test_gpu_shards_loopback(world, krings, precision, ksteps):
     tol = 1e-11 if precision == "f64" else 1e-5
     for s, st in zip(shards, steppers):
         n, c = st.get_owned()
-        assert rel_l2(n, n_ref[s.own_begin:s.own_end]) <= tol and rel_l2(c, c_ref[s.own_begin:s.own_end]) <= tol
+        parity(n, c, n_ref[s.own_begin:s.own_end], c_ref[s.own_begin:s.own_end], tol)
 
 
 @pytest.mark.gpu
@@ -186,7 +186,7 @@ def test_gpu_ranks_gloo(tmp_path, nu, nparts, world, krings, fuse, precision, ov
                  precision=precision, fuse=fuse)
     for r in res:
         b, e = int(r["own_begin"]), int(r["own_end"])
-        assert rel_l2(r["n"], n_ref[b:e]) <= 1e-11 and rel_l2(r["c"], c_ref[b:e]) <= 1e-11
+        parity(r["n"], r["c"], n_ref[b:e], c_ref[b:e], 1e-11)
         if overlap != "0" and fuse > 0:
             nI, nB, nG = r["classes"]
             assert nB > 0 and nG > 0 and (nI > 0 or nu < 32)      # the big case exercises all three classes
@@ -243,7 +243,7 @@ def test_rccl_world_of_one(tmp_path, fuse, krings, overlap, monkeypatch):
     res = launch(1, tmp_path, backend="hip", sphere=nu, nparts=nparts, krings=krings, steps=steps, precision="f64",
                  fuse=fuse, pg="nccl")[0]
     assert int(res["own_begin"]) == 0 and int(res["own_end"]) == len(n_ref)
-    assert rel_l2(res["n"], n_ref) <= 1e-11 and rel_l2(res["c"], c_ref) <= 1e-11
+    parity(res["n"], res["c"], n_ref, c_ref, 1e-11)
 
 
 @pytest.mark.gpu
@@ -276,3 +276,27 @@ def test_bench_survives_rccl_bringup_failure():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["scaling"] == "strong"
     assert "STAGED THROUGH THE HOST" in out["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps,warmup", [(20, 5), (100, 2)])
+def test_bench_self_launch_verifies_at_two_ranks(steps, warmup):
+    """`python bench.py --gpus 2` from a bare shell (no torchrun, WORLD_SIZE unset): the parent starts the two ranks
+    itself; the line carries `verify` of the gathered owned rows against the oracle (the state the timed region left
+    for <= 64 steps, a pre-run on the same plans for longer runs) and `config.sustained`"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "4"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "sphere10k",
+           "--steps", str(steps), "--warmup", str(warmup), "--sustained-steps", "60"]
+    res = subprocess.run(cmd, timeout=300, env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-2000:]
+    out = json.loads(lines[0])
+    v = out["verify"]
+    assert out["n_gpus"] == 2 and v["ok"] and v["state_changed"]
+    assert v["steps"] == (steps + warmup if steps + warmup <= 64 else 25)
+    assert v["rel_l2_n_deviation"] <= 1e-5 and v["rel_l2_n"] <= 1e-5
+    assert out["config"]["sustained"]["steps"] == 60 and out["config"]["sustained"]["value"] > 0
+    assert out["roofline"]["vertices_per_launch"] == "rank 0's owned rows"
