@@ -172,10 +172,14 @@ def test_config5_iteration_loop_vs_oracle(make, nparts, prec):
     case.dt_loop = min(0.08 * st0.maxEdgeLen ** 2, 0.8 * 0.2 / (max(1.0, case.model.D) * np.abs(st0.wVtx).max()))
     (n_ref, c_ref), e_ref = _config5_oracle(case, prec)
     tol = 1e-11 if prec == "f64" else 2e-5
+    # of the deviation from the homogeneous state: fp64 1e-9; fp32 1e-4 -- both sides build the operator from fp32
+    # geometry but by different (equivalent) formulas (cot = (|e|^2 - e.e')/|c| here, 1/tan(acos(.)) in the reference's
+    # order of operations there), so the weights differ in their last fp32 digits: observed 2.0e-5 after six iterations
+    tol_dev = None if prec == "f64" else 1e-4
     outs = {}
     for mode in ("sell", "tile", "fused", "fused+store"):
         (n, c), edges, plan = _config5_loop(case, prec, mode)
-        parity(n, c, n_ref, c_ref, tol, what=str((mode, rel_l2(n, n_ref), rel_l2(c, c_ref))))
+        parity(n, c, n_ref, c_ref, tol, tol_dev=tol_dev, what=mode)
         assert np.abs(np.array(edges) - np.array(e_ref)).max() <= (1e-12 if prec == "f64" else 2e-5) * max(e_ref), mode
         outs[mode] = (n, c)
         if mode == "fused+store":          # the stored operator is the one of the last deformation: one more plain step on it
@@ -183,7 +187,7 @@ def test_config5_iteration_loop_vs_oracle(make, nparts, prec):
             st = ol.Stats(case.topo, deformed(case.pts, 0.03, 0.9, 0.35 * 5), ol.F64 if prec == "f64" else ol.MIXED)
             n2, c2 = st.step(n_ref, c_ref, case.dt_loop, 1, case.model.as_array())
             g = plan.get_state()
-            parity(g[0], g[1], n2, c2, tol)
+            parity(g[0], g[1], n2, c2, tol, tol_dev=tol_dev)
     # fused and unfused apply the same coefficients in the same order (two kernels: the compiler may contract a
     # multiply-add differently, hence a few ulp, not bit for bit)
     for other in ("sell", "fused+store"):

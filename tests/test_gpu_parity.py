@@ -31,6 +31,14 @@ pytestmark = pytest.mark.gpu
 TOL_REF = 3e-8
 TOL_F64 = 1e-11
 TOL_F32 = 1e-5
+# fp32 plans, error relative to the DEVIATION ||n_ref - nMax|| (helpers.parity's second bar; default 1e-5 of it, which the
+# rough random initial condition of main.cpp:182-186 meets: bench.py's 25 steps at 16.4M give 1.1e-7).  From a SMOOTH
+# initial condition fp32 cannot hold that: n's deviation decays to a quasi-equilibrium r*dn ~ -alpha*lap(dc), and the
+# Laplacian of a smooth fp32 field is a second difference of nearly equal numbers (w ~ 1/h^2, c_j - c_i ~ 1e-6 at a
+# rounding of 7e-11), so the error of n is ~1e-3 of the (small) deviation of n while c stays at ~5e-6 of its own.  The
+# bars below are ~5x the observed values (MI355X, round 3), kept next to each call; a regression of one order shows.
+DEV_SMOOTH_100 = 1e-3        # observed 1.4e-4 (sphere nu=32), 6.0e-5 (strip), 5.5e-4 (nu=64) after 100 steps
+DEV_SMOOTH_LARGE = 1e-2      # observed 2.1e-3 (1M, 20 steps), 1.6e-3 (16.4M, 12 steps), 1.8e-3 (irregular, 100 steps)
 
 
 def _ref_device(case):
@@ -131,7 +139,9 @@ def test_native_plan_clamp_and_custom_model(ksteps):
     n2, c2 = plan2.get_state()
     r2 = case.ostats(ol.F64).step(nb.astype(np.float32).astype(np.float64), cb.astype(np.float32).astype(np.float64), case.dt, 5,
                                   model.as_array())
-    parity(n2, c2, r2[0], r2[1], TOL_F32, nMax=1.7)
+    # c0 = 1/(1+n) is far from the base state nMax/(1+nMax) here, so c is stored as a LARGE fp32 deviation (-0.26) and
+    # its rounding feeds n through alpha*lap(c): observed 1.1e-4 of n's deviation
+    parity(n2, c2, r2[0], r2[1], TOL_F32, nMax=1.7, tol_dev=1e-3)
 
 
 def test_reference_step_limits_and_errors():
@@ -177,7 +187,7 @@ def test_native_plan_f32_100_steps(make, nparts):
     # the fp32 path starts from the fp32-rounded state; give the oracle the same start
     n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
     n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
-    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32)
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32, tol_dev=DEV_SMOOTH_100)
 
 
 def test_native_plan_f32_random_ic_and_mixed_oracle():
@@ -192,7 +202,8 @@ def test_native_plan_f32_random_ic_and_mixed_oracle():
     n0r, c0r = case.n0.astype(np.float32).astype(np.float64), case.c0.astype(np.float32).astype(np.float64)
     for prec in (ol.F64, ol.MIXED):
         n_ref, c_ref = case.ostats(prec).step(n0r, c0r, case.dt, 100, case.model.as_array())
-        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32)
+        # 100 steps: the rough part of the random IC has diffused away; observed 1.8e-5 of the deviation (n and c)
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32, tol_dev=1e-4)
 
 
 def test_native_plan_ragged_sizes():
@@ -249,7 +260,7 @@ def test_native_plan_full_size_properties(ksteps):
     plan64.set_state(n0.astype(np.float32), c0.astype(np.float32))
     plan64.run(20, dt, model)
     n64, c64 = plan64.get_state()
-    parity(outs[0][0], outs[0][1], n64, c64, TOL_F32)
+    parity(outs[0][0], outs[0][1], n64, c64, TOL_F32, tol_dev=DEV_SMOOTH_LARGE)
     # (iv)
     rgba, rgb, lo, hi = plan.format()
     n = outs[0][0]
@@ -314,7 +325,7 @@ def test_fused_tile_plan_f32_matches_single_step_plan():
     parity(outs[0][0], outs[0][1], outs[1][0], outs[1][1], 1e-6)
     n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
     n_ref, c_ref = case.ostats(ol.F64).step(n0r, c0r, case.dt, 100, case.model.as_array())
-    parity(outs[0][0], outs[0][1], n_ref, c_ref, TOL_F32)
+    parity(outs[0][0], outs[0][1], n_ref, c_ref, TOL_F32, tol_dev=5 * DEV_SMOOTH_100)
 
 
 def test_irregular_mesh_all_paths():
@@ -356,7 +367,7 @@ def test_irregular_mesh_all_paths():
         plan.set_state(n0, c0)
         plan.run(100, dt, case.model)
         n_gpu, c_gpu = plan.get_state()
-        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32)
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32, tol_dev=DEV_SMOOTH_LARGE)
 
 
 def test_irregular_mesh_small_tiles_and_sharded_plan():
@@ -429,7 +440,7 @@ def test_config3_full_size_properties():
     p64.set_state(n0.astype(np.float32), c0.astype(np.float32))
     p64.run(12, dt, model)
     d = p64.get_state()
-    parity(a[0], a[1], d[0], d[1], TOL_F32)
+    parity(a[0], a[1], d[0], d[1], TOL_F32, tol_dev=DEV_SMOOTH_LARGE)
 
 
 def test_edge_cases_isolated_vertices_and_tiny_meshes():
@@ -605,7 +616,7 @@ def test_fused_plan_on_multilevel_partition(prec):
         plan.run(13, dt, case.model)
         n_gpu, c_gpu = plan.get_state()
         tol = TOL_F64 if prec == "f64" else TOL_F32
-        parity(n_gpu, c_gpu, n_ref, c_ref, tol)
+        parity(n_gpu, c_gpu, n_ref, c_ref, tol, tol_dev=None if prec == "f64" else 1e-4)   # smooth IC, 13 steps: observed 1.1e-5
     if prec == "f64":
         case = Case(*fa.make_icosphere(24, 0.1), 24, method="multilevel")
         lay, dev = _ref_device(case)
