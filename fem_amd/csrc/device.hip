@@ -104,6 +104,7 @@ struct fem_plan {
   DevBuf<fem_uint> slice_off, idx, send_idx;
   // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
   int ksteps = 0, tcfg = 0;
+  int device = -1;                  // ordinal of the GPU that was current when the plan was created (owns every buffer)
   int prologue = -1, sell_nt = -1;   // FEM_TILE_PROLOGUE / FEM_SELL_NT as read when the plan was created (-1: by operator size)
   fem_uint ntiles = 0, maxLocal = 0, maxExtra = 0;
   fem_uint nInterior = 0, nBoundary = 0, nGhost = 0;   // tile classes of a shard's plan, in this order
@@ -235,6 +236,8 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
                     : (pro == 1 ? tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, XV, 0>);
   };
   auto kern = p->maxExtra ? pick(std::integral_constant<int, 2>()) : pick(std::integral_constant<int, 1>());
+  // Plans with 12-byte records exist in two prologue variants only: plain loads (1) and nontemporal loads (3);
+  // FEM_TILE_PROLOGUE = 0 runs as 1 and 2 as 3 there (the knob's other values only reorder four-float loads).
   if constexpr (sizeof(T) == 4 && (C == kDefaultTileCfg || C == kDefaultTileCfgWide)) {
     if (p->packed)
       kern = p->maxExtra ? (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 3, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 1, 1>)
@@ -601,6 +604,7 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     if (rc != FEM_OK) return fail(rc, "fem_plan_create: mesh too large");
   }
   fem_plan *p = new fem_plan();
+  (void)hipGetDevice(&p->device);
   p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
   p->precision = precision; p->V = op.V;
   if (const char *e = getenv("FEM_TILE_PROLOGUE")) p->prologue = std::min(3, std::max(0, atoi(e)));
@@ -634,7 +638,6 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     bool packed = precision == FEM_PREC_F32 && !(flags & FEM_PLAN_DEVICE_ASSEMBLY) &&
                   (tcfg == kDefaultTileCfg || tcfg == kDefaultTileCfgWide) && !(pkEnv && !strcmp(pkEnv, "0"));
     if (packed) {
-      const size_t entries = TL.coef.size() / 4;
       std::vector<float> c32(TL.coef.begin(), TL.coef.end());
       fem::uint *words = reinterpret_cast<fem::uint *>(c32.data());
       constexpr int kQ = (1 << 20) - 1;
@@ -677,7 +680,6 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
         p->packed = true;
         p->tile_bytes -= recWords * 4;                       // 12-byte records ...
         p->tile_bytes += scaleWords * 4;                     // ... and one scale per row
-        (void)entries;
       }
     }
     if (!packed) uploadCoef(&p->tcoef, TL.coef);
@@ -1190,9 +1192,13 @@ constexpr int kMaxDevices = 64;
 static double *g_scratch_ptr[kMaxDevices];
 static std::mutex g_scratch_mutex;
 
-static int formatScratch(double **out) {
+static int formatScratch(const fem_plan *p, double **out) {
   int dev = -1;
   HIP_TRY(hipGetDevice(&dev));
+  // the kernels run on the current device against that device's copy of the array: the plan's buffers must live there
+  if (p->device >= 0 && dev != p->device)
+    return fail(FEM_ERR_INVALID, ("fem_plan_format_noalloc: the plan was created on GPU " + std::to_string(p->device) +
+                                  " but GPU " + std::to_string(dev) + " is current (hipSetDevice to the plan's device first)").c_str());
   if (dev < 0 || dev >= kMaxDevices) return fail(FEM_ERR_LIMIT, "fem_plan_format_noalloc: device ordinal beyond 63");
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   if (!g_scratch_ptr[dev]) {
@@ -1212,12 +1218,13 @@ int fem_plan_format_noalloc(fem_plan *p, fem_uint nverts, uint64_t dev_rgba, uin
   if (!dev_rgba || (dev_rgba & 31u)) return fail(FEM_ERR_INVALID, "fem_plan_format_noalloc: dev_rgba must be a 32-byte aligned device buffer of 4 * nverts doubles");
   if (dev_minmax & 7u) return fail(FEM_ERR_INVALID, "fem_plan_format_noalloc: dev_minmax must be 8-byte aligned");
   double *ws = nullptr;
-  const int rc = formatScratch(&ws);
+  const int rc = formatScratch(p, &ws);
   if (rc != FEM_OK) return rc;
   double *part = ws, *mm = ws + 2 * kFormatMaxBlocks;
   const fem_uint V = nverts, nb = std::min<fem_uint>((V + 255) / 256, kFormatMaxBlocks);
   hipStream_t st = (hipStream_t)stream;
   double4 *out = (double4 *)dev_rgba;
+  (void)hipGetLastError();        // an earlier call's error is not this call's: only what these launches raise is reported
   // every block writes its own partial pair and the final kernel reads exactly nb of them: nothing in the array
   // has to start at zero, whatever the previous call left there
   if (p->precision == FEM_PREC_F32) hipLaunchKernelGGL(minmax_kernel<float2>, dim3(nb), dim3(256), 0, st, (const float2 *)p->state[p->cur], V, part);

@@ -230,7 +230,7 @@ int waitExchange(fem_dist *d, hipStream_t stream) {
 int runOverlapped(fem_dist *d, int nsteps, double dt, const fem_model *model, hipStream_t stream) {
   const fem_uint nI = d->nI, nB = d->nB, nG = d->nG;
   fem_plan *p = d->plan;
-  hipStream_t side = d->side;             // high-priority stream of the boundary tiles + pack (null: all on `stream`)
+  hipStream_t side = d->side;             // stream of the boundary tiles + pack (null: all on `stream`)
   for (int done = 0; done < nsteps;) {
     const int s = std::min(std::min(d->ksteps, d->budget), nsteps - done);
     const bool first = d->pending, last = d->budget == s;
@@ -453,15 +453,12 @@ int fem_dist_create(fem_plan *plan, const fem_shard *shard, void *comm, fem_dist
   if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evDone, hipEventDisableTiming);
   const char *bsEnv = getenv("FEM_BOUNDARY_STREAM");
   if (e == hipSuccess && d->classes && !(bsEnv && !strcmp(bsEnv, "0"))) {
-    int lo = 0, hi = 0;
-    e = hipDeviceGetStreamPriorityRange(&lo, &hi);        // hi = the numerically lowest value = greatest priority
-    // Normal priority unless FEM_SIDE_PRIORITY=high.  A high-priority side stream starts the boundary tiles a little
-    // earlier (8-GPU rehearsal 6.25x instead of 6.22x), but on this ROCm 7.2 / MI355X pool several host threads of one
-    // process, each with a high-priority stream that waits for events of normal-priority streams, stalled for seconds
-    // and now and then for good (tools/inproc_hang_probe.sh: 1 run in ~17 never finished; 0 of 240 at normal priority).
-    const char *pr = getenv("FEM_SIDE_PRIORITY");
-    const int prio = pr && !strcmp(pr, "high") ? hi : 0;
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, prio);
+    // Normal priority, always ("the side-stream stall"): a side stream at the greatest priority
+    // gained nothing measurable (8-GPU rehearsal 6.20x against 6.21-6.24x) and, with three or four ranks of one process
+    // each holding one, starved the normal-priority streams its own waits depended on -- 1 run in ~17 never finished,
+    // with 16 hardware queues as with 4, with host-ordered copies as with event-ordered ones; 0 of 240 at normal
+    // priority.  The knob that brought it back (FEM_SIDE_PRIORITY) is gone.
+    e = hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evTop, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&d->evSide, hipEventDisableTiming);
   }

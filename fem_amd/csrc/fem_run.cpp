@@ -41,7 +41,7 @@ struct Options {
   int ranks = 0, krings = 0, precision = FEM_PREC_F32;
   int imex = 0;                      // --imex ITERS: semi-implicit steps, ITERS CG iterations each (sharded mode)
   double dtScale = 1.0;              // --dt-scale: time step = scale x 0.1 maxEdgeLen^2
-  double watchdog = 0;               // --watchdog SECONDS: a sharded run that has not finished by then reports where every rank is and exits 124
+  double watchdog = -1;              // --watchdog SECONDS (sharded runs; default 600, 0 = off): a run that has not finished by then reports where every rank is and exits 124
   bool inproc = false;
   std::string dump;                  // raw doubles: n[V] then c[V] of the final state, ordered numbering
 };
@@ -272,6 +272,10 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
   if (n < R) { std::fprintf(stderr, "--ranks %d needs at least that many partitions (have %d)\n", R, n); return -1; }
   const int krings = o.krings > 0 ? o.krings : (o.imex > 0 ? 1 : std::max(2, 2 * o.fuse));
   const int ndev = std::max(1, fem_dist_device_count());
+  if (!o.inproc && R > ndev) {     // RCCL refuses (or hangs on) two ranks of one communicator on the same GPU
+    std::fprintf(stderr, "--ranks %d over RCCL needs that many GPUs (this host shows %d); --transport inproc lets ranks share one\n", R, ndev);
+    return -1;
+  }
   char uid[128] = {0};
   fem_dist_world *world = nullptr;
   if (o.inproc) { if (!ok(fem_dist_world_create(R, &world), "world")) return -1; }
@@ -295,10 +299,13 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
   std::condition_variable wdCv;
   bool wdDone = false;
   std::thread watchdog;
-  if (o.watchdog > 0)
+  // sharded runs always have one (default 600 s, --watchdog 0 turns it off): a rank stuck in a collective or waiting
+  // for the GPU must end the process with a message and a non-zero status, not hang its caller
+  const double wdSeconds = o.watchdog < 0 ? 600.0 : o.watchdog;
+  if (wdSeconds > 0)
     watchdog = std::thread([&]() {
       std::unique_lock<std::mutex> lock(wdMutex);
-      if (wdCv.wait_for(lock, std::chrono::duration<double>(o.watchdog), [&] { return wdDone; })) return;
+      if (wdCv.wait_for(lock, std::chrono::duration<double>(wdSeconds), [&] { return wdDone; })) return;
       for (int i = 0; i < R; i++) std::fprintf(stderr, "watchdog: rank %d is at: %s\n", i, stage[i].load());
       std::fflush(stderr);
       std::_Exit(124);
@@ -333,12 +340,20 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
       for (fem_uint i = 0; i < nLocal; i++) { ln[i] = r.nFn[l2g[i]]; lc[i] = r.cFn[l2g[i]]; }
       stage[rank] = "set-up: upload";
       if (fem_plan_set_state(plan, ln.data(), lc.data()) != FEM_OK) { bail("upload", false); break; }
-      stage[rank] = "set-up: streams and communicator";
+      stage[rank] = "set-up: stream";
       if (fem_dist_stream_create(&stream) != FEM_OK) { bail("stream", true); break; }
-      if (!o.inproc && fem_dist_rccl_comm_create(uid, rank, R, &comm) != FEM_OK) { bail("RCCL communicator", true); break; }
-      if (fem_dist_create(plan, shard, comm, world, &dist) != FEM_OK) { bail("fem_dist_create", true); break; }
       up = true;
     } while (false);
+    // ncclCommInitRank is a collective: a rank that failed above would leave the others waiting inside it for ever,
+    // so all ranks meet first and nobody creates a communicator unless everybody got this far
+    stage[rank] = "local set-up done, waiting for the other ranks";
+    bar.wait();
+    if (failed) up = false;
+    if (up) {
+      stage[rank] = "set-up: communicator";
+      if (!o.inproc && fem_dist_rccl_comm_create(uid, rank, R, &comm) != FEM_OK) { bail("RCCL communicator", true); up = false; }
+      else if (fem_dist_create(plan, shard, comm, world, &dist) != FEM_OK) { bail("fem_dist_create", true); up = false; }
+    }
     stage[rank] = "set-up done, waiting for the other ranks";
     bar.wait();                                        // every rank is set up (or has failed)
     if (failed) up = false;
@@ -432,7 +447,8 @@ int usage() {
                "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering);\n"
                "                   --imex ITERS: semi-implicit steps (diffusion by ITERS CG iterations, dot products all-reduced\n"
                "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2;\n"
-               "                   --watchdog SECONDS: if the run has not finished by then, say where every rank is and exit 124\n"
+               "                   --watchdog SECONDS (default 600, 0 = off): if the run has not finished by then, say where every rank\n"
+               "                   is and exit 124\n"
                "                   (FEM_DIST_TRACE=1: one stderr line per exchange stage)\n");
   return 2;
 }

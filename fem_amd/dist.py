@@ -393,14 +393,12 @@ class ShardedRun:
 
     def _side_stream(self, stream):
         """stream for the boundary tiles + pack + exchange of a group (None: CPU steppers, the null stream,
-        FEM_BOUNDARY_STREAM=0).  Normal priority unless FEM_SIDE_PRIORITY=high: a high-priority stream that waits for
-        events of normal-priority streams stalled, now and then for good, when several host threads of one process
-        each had one (fem_amd/csrc/dist.cpp, tools/inproc_hang_probe.sh); the gain was 6.22x -> 6.25x in the rehearsal."""
+        FEM_BOUNDARY_STREAM=0).  Normal priority: see fem_amd/csrc/dist.cpp and DESIGN.md section 5 for why not high."""
         if stream is None or not isinstance(self.stepper, HipShardStepper) or os.environ.get("FEM_BOUNDARY_STREAM", "1") == "0":
             return None
         if getattr(self, "_side", None) is None:
             import torch
-            self._side = torch.cuda.Stream(priority=-1 if os.environ.get("FEM_SIDE_PRIORITY") == "high" else 0)
+            self._side = torch.cuda.Stream()
             self._ev_top, self._ev_side = torch.cuda.Event(), torch.cuda.Event()
             self._side_busy = False
         return self._side

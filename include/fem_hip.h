@@ -314,7 +314,8 @@ int fem_plan_format(fem_plan *p, fem_uint nverts, double *rgba, unsigned char *r
  * It calls no hipMalloc/hipFree and no synchronisation.  nverts <= 67 108 864 (FEM_ERR_LIMIT beyond: the array
  * is sized for that).  All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams,
  * two threads) race; calls ordered on one stream do not.  The first call on a device looks the array's address up
- * (make it outside a graph capture). */
+ * (make it outside a graph capture).  The GPU the plan was created on must be the current device (FEM_ERR_INVALID
+ * otherwise: the kernels would run against another GPU's copy of the array), and `stream` a stream of that GPU. */
 int fem_plan_format_noalloc(fem_plan *p, fem_uint nverts, uint64_t dev_rgba, uint64_t dev_minmax, void *stream);
 /* geometry of a tiled plan: fused steps, tile count, largest tile (rows staged in LDS), operator
  * rows loaded per launch (sum over tiles), workgroup size and rows per thread; ksteps = 0 for a

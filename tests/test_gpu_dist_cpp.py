@@ -90,6 +90,28 @@ def test_ranks_as_threads_on_one_gpu(sphere_off, reference, tmp_path, ranks, fus
     parity(n, c, n_ref, c_ref, 1e-11)
 
 
+@pytest.mark.parametrize("ranks,fuse,rings,packed", [(2, 4, 8, None), (3, 4, 4, None), (3, 4, 4, "0")])
+def test_fp32_shards_against_the_f64_oracle(sphere_off, reference, tmp_path, ranks, fuse, rings, packed, monkeypatch):
+    """fp32 shard plans -- 12-byte operator records in boundary, ghost and interior tiles by default, four floats with
+    FEM_TILE_PACKED=0 -- against the f64 oracle (not against another packed plan, where a packing fault in the ghost or
+    boundary tiles would cancel out): the fp32 bar on the fields, and on the deviation (random IC, 20 steps; observed
+    n 1.5e-7, c 9e-8 of the deviation with either record format)"""
+    part, (n_ref, c_ref) = reference
+    if packed is not None:
+        monkeypatch.setenv("FEM_TILE_PACKED", packed)
+    n, c, out = run_ranks(sphere_off, tmp_path, ranks, fuse, rings, "inproc", None, f64=False)
+    assert "Ranks: %d (in-process copies" % ranks in out
+    parity(n, c, n_ref, c_ref, 1e-5)
+    assert rel_l2(n, n_ref) > 1e-12                 # fp32 did run (an f64 plan would be at 1e-14)
+
+
+def test_rccl_refuses_more_ranks_than_gpus(sphere_off):
+    """two ranks of one RCCL communicator on the same GPU are refused up front (RCCL rejects or hangs on duplicates)"""
+    cmd = [FEM_RUN, sphere_off, "--ranks", "2", "-n", str(NPARTS), "--fuse", "4", "--iterations", "2", "--transport", "rccl"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "needs that many GPUs" in res.stderr, res.stderr[-1500:]
+
+
 def test_python_driver_agrees_with_cpp_host(sphere_off, reference, tmp_path):
     """fem_amd/dist.py:ShardedRun (torch.distributed, backend nccl, world 1) and fem_run --ranks 1 (RCCL from C++)
     drive the same plans through the same schedule: same state, fp32"""
