@@ -41,7 +41,7 @@ WORKLOADS = {                       # class-I geodesic spheres, edge ~ 0.1 (BASE
     "scan8m": dict(nu=900, verts_per_part=256, scanned=True),
     "scan500k": dict(nu=224, verts_per_part=256, scanned=True),
     # config 5: deforming mesh, the operator re-assembled on the device every time step (one iteration =
-    # deform kernel + fused assembly-and-step kernel); N = 1 only
+    # deform kernel + fused assembly-and-step kernel); N > 1: shards with 4 ghost rings, state exchanged every 4 iterations
     "deform4m": dict(nu=640, verts_per_part=256, deform=True),
     "deform250k": dict(nu=160, verts_per_part=256, deform=True),
 }
@@ -400,10 +400,12 @@ def main():
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     deform = wl.get("deform", False)
     if deform:
-        if world > 1:
-            raise SystemExit("bench.py: the deforming-mesh workloads run on one GPU")
-        args.fuse, nparts = 0, max(1, V_total // wl["verts_per_part"])
-        runner = fdist.DeformRun(mesh, nparts, args.precision, fused=not args.unfused)
+        args.fuse, nparts = 0, max(world, V_total // wl["verts_per_part"])
+        if world > 1:       # ghost positions deform locally; only the state is exchanged, every FEM_HALO_RINGS iterations
+            runner = fdist.ShardedDeformRun(mesh, nparts, rank, world, args.precision, fused=not args.unfused,
+                                            control_group=control)
+        else:
+            runner = fdist.DeformRun(mesh, nparts, args.precision, fused=not args.unfused)
     elif world > 1:
         runner = fdist.ShardedRun(mesh, nparts, rank, world, args.precision, ksteps=args.fuse, dt_rule=dt_rule,
                                   control_group=control)
@@ -531,7 +533,8 @@ def main():
         achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch * (args.steps / launches) / (kernel_ms * 1e-3) / 1e9
         if deform:        # the assembly is the dominant kernel: 68 B per element by SURVEY.md 8(d)
             kernel_ms = asm_ms
-            achieved = ALG_BYTES_PER_ELEMENT_ASSEMBLY * n_faces / (kernel_ms * 1e-3) / 1e9
+            # (a shard assembles the rows of its local vertices: its share of the elements is priced by its owned rows)
+            achieved = ALG_BYTES_PER_ELEMENT_ASSEMBLY * n_faces * (v_per_launch / V_total) / (kernel_ms * 1e-3) / 1e9
         traffic, traffic_source = runner.measured_traffic()
         out = {
             "metric": "DOF-iterations/s", "value": 2.0 * V_total * args.steps / wall, "unit": "DOF-iterations/s",

@@ -1051,6 +1051,17 @@ int fem_plan_assemble_step(fem_plan *p, double dt, const fem_model *model, int s
 
 int fem_plan_deform(fem_plan *p, double amplitude, double wavenumber, double phase, void *stream) {
   if (!p || !p->can_assemble) return fail(FEM_ERR_INVALID, "fem_plan_deform: plan was not created with FEM_PLAN_DEVICE_ASSEMBLY");
+  if (!p->rows_are_vertices) {           // a shard's plan: only the vertices its rows stand for
+    const dim3 rgrid((p->V + 255) / 256);
+    if (p->precision == FEM_PREC_F32)
+      hipLaunchKernelGGL(deform_rows_kernel<float>, rgrid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos0, (float4 *)p->pos,
+                         p->rowg.p, p->V, (float)amplitude, (float)wavenumber, (float)phase);
+    else
+      hipLaunchKernelGGL(deform_rows_kernel<double>, rgrid, dim3(256), 0, (hipStream_t)stream, (const double4 *)p->pos0, (double4 *)p->pos,
+                         p->rowg.p, p->V, amplitude, wavenumber, phase);
+    HIP_TRY(hipGetLastError());
+    return FEM_OK;
+  }
   const dim3 grid((p->Vg + 255) / 256);
   if (p->precision == FEM_PREC_F32)
     hipLaunchKernelGGL(deform_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float4 *)p->pos0, (float4 *)p->pos,

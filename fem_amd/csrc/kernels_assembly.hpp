@@ -492,6 +492,21 @@ __global__ __launch_bounds__(256) void assemble_step_sell_kernel(const typename 
   block_max_256((double)me, blockMax);
 }
 
+// the same displacement for the vertices of a plan's rows only (a shard's plan: rowg[r] = mesh vertex of local row r;
+// every position its rows' faces read belongs to one of its rows, so the other ranks' vertices stay untouched)
+template <typename T>
+__global__ __launch_bounds__(256) void deform_rows_kernel(const typename Vec<T>::t4 *__restrict__ base,
+                                                          typename Vec<T>::t4 *__restrict__ pos, const uint *__restrict__ rowg,
+                                                          uint nrows, T amp, T q, T phase) {
+  const uint r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  const uint i = rowg[r];
+  typename Vec<T>::t4 p = base[i];
+  const T s = (T)1 + amp * sin(q * p.x + phase) * cos(q * p.y - (T)0.5 * phase) * sin(q * p.z + (T)0.25 * phase);
+  p.x *= s; p.y *= s; p.z *= s;
+  pos[i] = p;
+}
+
 // seeded smooth radial displacement of the base positions (BASELINE config 5: deforming mesh)
 template <typename T>
 __global__ __launch_bounds__(256) void deform_kernel(const typename Vec<T>::t4 *__restrict__ base,

@@ -133,6 +133,87 @@ class DeformRun:
         return (hit.get("hbm_bytes_per_launch"), hit.get("source")) if isinstance(hit, dict) else (None, None)
 
 
+class ShardedDeformRun:
+    """BASELINE config 5 on shards: every rank deforms the vertices of its own rows (owned + k ghost rings; the
+    deformation is a function of the base position, so ghost positions need no exchange), re-assembles the operator
+    rows of its local vertices and takes the time step in one kernel (fem_plan_assemble_step), k iterations between
+    two halo exchanges of the STATE (rows of ring j are exact for j <= k - s after s iterations, as in ShardedRun)."""
+    def __init__(self, mesh, nparts, rank, world, precision="f32", seed=1, krings=4, fused=True, control_group=None):
+        self.kernel_name = "assemble_step_sell_kernel" if fused else "assemble_rows_sell_kernel"
+        self.fused = fused
+        self.part = _partition(mesh, nparts)
+        om = self.part.ordered
+        self.model = fa.default_model()
+        self.precision = precision
+        self.krings = int(os.environ.get("FEM_HALO_RINGS", str(krings)))
+        self.shard = fa.Shard(self.part, rank, world, self.krings)
+        om.init_stats_shard(fa.PREC_F64, self.shard)
+        self.dt = 0.08 * om.stats()["maxEdgeLen"] ** 2           # maxEdgeLen is the whole mesh's on every rank
+        self.seed = seed
+        n0, c0 = fa.initial_condition(om.V, seed)
+        l2g = self.shard.loc2glob
+        self.stepper = HipShardStepper(om, self.shard, precision, self.model, n0[l2g], c0[l2g], part=self.part, ksteps=0,
+                                       assemble=True)
+        self.plan = self.stepper.plan
+        self.V, self.F = om.V, om.F
+        self.vertices_per_launch = self.shard.n_own
+        self.steps_per_launch = 1
+        self.amp, self.q, self.dphase = 0.01, 2 * np.pi / 4.0, 0.01
+        self.iteration = 0
+        self.budget = self.krings
+        self.layout_bytes_per_launch = None
+        self.host_group, self.fallback_reason = None, None
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and world > 1:
+            err = None
+            try:
+                exchange_halo(self.stepper, self.shard, None)      # brings the communicator up outside the timed region
+            except Exception as ex:                                # noqa: BLE001
+                if control_group is None:
+                    raise
+                err = ex
+            if control_group is not None:
+                import torch
+                failed = torch.tensor([0 if err is None else 1])
+                dist.all_reduce(failed, op=dist.ReduceOp.MAX, group=control_group)
+                if int(failed.item()):
+                    self.host_group = control_group
+                    self.fallback_reason = ("%s: %s" % (type(err).__name__, str(err).strip().splitlines()[0][:160])
+                                            if err is not None else "RCCL failed on another rank")
+                    exchange_halo(self.stepper, self.shard, None, host_group=control_group)
+
+    def run(self, nsteps, stream=None, deform=True):
+        s = stream.cuda_stream if stream is not None else None
+        for _ in range(nsteps):
+            if self.budget == 0:
+                exchange_halo(self.stepper, self.shard, stream, host_group=self.host_group)
+                self.budget = self.krings
+            if deform:
+                self.plan.deform(self.amp, self.q, self.dphase * self.iteration, s)
+            if self.fused:
+                self.plan.assemble_step(self.dt, self.model, False, s)
+            else:
+                self.plan.assemble(s)
+                self.plan.run(1, self.dt, self.model, s)
+            self.iteration += 1
+            self.budget -= 1
+
+    def get_owned(self):
+        return self.stepper.get_owned()
+
+    def reset(self):
+        n0, c0 = fa.initial_condition(self.V, self.seed)
+        l2g = self.shard.loc2glob
+        self.plan.set_state(n0[l2g], c0[l2g])
+        self.iteration, self.budget = 0, self.krings
+
+    def traffic_key(self):
+        return "%s:%s:shard %d of %d" % (self.kernel_name, self.precision, self.shard.rank, self.shard.nranks)
+
+    def measured_traffic(self):
+        return None, None
+
+
 class _DevView:
     """zero-copy view of device memory owned by the library, for torch.as_tensor"""
 
@@ -143,12 +224,12 @@ class _DevView:
 class HipShardStepper:
     """one rank's sharded plan on its GPU"""
 
-    def __init__(self, ordered, shard, precision, model, n_loc, c_loc, part=None, ksteps=0):
+    def __init__(self, ordered, shard, precision, model, n_loc, c_loc, part=None, ksteps=0, assemble=False):
         import torch
         self.torch = torch
         self.shard = shard
         self.plan = fa.Plan(ordered, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, model, shard=shard,
-                            part=part, ksteps=ksteps)
+                            part=part, ksteps=ksteps, assemble=assemble)
         self.plan.set_state(n_loc, c_loc)
         self.dtype = torch.float32 if precision == "f32" else torch.float64
         self.typestr = "<f4" if precision == "f32" else "<f8"

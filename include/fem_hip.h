@@ -269,7 +269,9 @@ int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_part
 /* vertex positions of the ordered mesh (3 doubles per vertex): new base positions + current positions */
 int fem_plan_set_points(fem_plan *p, const double *points);
 /* current positions = base positions scaled radially by 1 + amplitude * sin(q x + phase) cos(q y - phase/2)
- * sin(q z + phase/4) (q = wavenumber): the seeded smooth deformation of BASELINE config 5 */
+ * sin(q z + phase/4) (q = wavenumber): the seeded smooth deformation of BASELINE config 5.  A shard's plan moves the
+ * vertices of its own rows (owned + ghost) only: the deformation is a function of the base position, so ghost rows
+ * deform locally and no exchange of positions is needed */
 int fem_plan_deform(fem_plan *p, double amplitude, double wavenumber, double phase, void *stream);
 /* Device assembly from the current positions, two kernels, async on `stream`:
  * per element: corner angles + cotangents (computeAngles, mesh_function.cpp:70-160), area

@@ -89,3 +89,47 @@ def stable_dt(stats, model, safety=0.2):
     """explicit-Euler step well inside the diffusion limit of an irregular mesh (the reference's
     dt = 0.1 maxEdgeLen^2 assumes near-uniform triangles)"""
     return safety / (max(1.0, model.D) * np.abs(np.asarray(stats.wVtx)).max())
+
+
+def pathological_scan(nu=40, seed=3):
+    """what real scans bring that the synthetic workloads lack (BASELINE config 4; no scan data ships with the reference
+    or this image): open boundaries (three holes cut into the irregular scanned-like sphere), vertices left without any
+    face (inside the holes, plus two stray points), and a non-manifold (bow-tie) vertex -- a small closed fan glued to
+    the surface by one vertex alone.  Valences 3..16 as in make_scanned_like."""
+    pts, tri = fa.make_scanned_like(nu, 0.1, seed=seed, high_valence_fraction=0.01)
+    V = len(pts)
+    c = pts / np.linalg.norm(pts, axis=1)[:, None]
+    inhole = np.zeros(V, bool)
+    for d, w in (((1, 0.2, 0.1), 0.97), ((-0.3, 1, 0.5), 0.985), ((0, -0.4, -1), 0.99)):
+        d = np.array(d, float) / np.linalg.norm(d)
+        inhole |= c @ d > w
+    tri = tri[~inhole[tri].any(axis=1)]
+    v0 = int(tri[0, 0])
+    p0 = pts[v0]
+    nrm = p0 / np.linalg.norm(p0)
+    a = np.cross(nrm, [0.3, 0.5, 0.8])
+    a /= np.linalg.norm(a)
+    b = np.cross(nrm, a)
+    extra = np.array([p0 + 0.1 * nrm + 0.05 * a, p0 + 0.1 * nrm - 0.025 * a + 0.043 * b, p0 + 0.1 * nrm - 0.025 * a - 0.043 * b])
+    e = V + np.arange(3)
+    fan = np.array([[v0, e[0], e[1]], [v0, e[1], e[2]], [v0, e[2], e[0]], [e[0], e[2], e[1]]], np.uint32)
+    pts = np.vstack([pts, extra, [[0.0, 0.0, 0.0], [9.0, 9.0, 9.0]]])
+    return pts, np.vstack([tri, fan]).astype(np.uint32)
+
+
+def write_binary_ply(path, pts, tri):
+    """binary little-endian PLY the way scanners write it: float positions, per-vertex normals and colours the solver
+    must skip, faces as uchar-counted int lists"""
+    with open(path, "wb") as f:
+        f.write(("ply\nformat binary_little_endian 1.0\ncomment scan-like test surface\nelement vertex %d\n"
+                 "property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+                 "property uchar red\nproperty uchar green\nproperty uchar blue\nelement face %d\n"
+                 "property list uchar int vertex_indices\nend_header\n" % (len(pts), len(tri))).encode())
+        rec = np.zeros(len(pts), dtype=[("p", "<f4", 3), ("n", "<f4", 3), ("c", "u1", 3)])
+        rec["p"] = pts
+        rec["n"] = pts / np.maximum(np.linalg.norm(pts, axis=1), 1e-30)[:, None]
+        rec["c"] = 128
+        f.write(rec.tobytes())
+        fr = np.empty(len(tri), dtype=[("n", "u1"), ("v", "<i4", 3)])
+        fr["n"], fr["v"] = 3, tri
+        f.write(fr.tobytes())

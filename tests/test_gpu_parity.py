@@ -625,3 +625,49 @@ def test_fused_plan_on_multilevel_partition(prec):
         n_gpu, c_gpu = dev.get_state()
         n_ref, c_ref = case.ostats(ol.MIXED).step(case.n0, case.c0, case.dt, 4, case.model.as_array())
         parity(n_gpu, c_gpu, n_ref, c_ref, TOL_REF)
+
+
+def test_scan_pathologies_all_paths(tmp_path):
+    """BASELINE config 4 with what REAL scans bring (helpers.pathological_scan: open boundaries, vertices without
+    faces, a non-manifold bow-tie vertex, valences 3..16), read back from a scanner-style binary PLY (normals and
+    colours to skip) and upsampled once: the drop-in `step`, the sliced-ELL plan and the fused plan (f64 and f32, wide
+    rows through the LDS extras, boundary rows with open fans) against the oracle.  No real scan data can be fetched
+    here, so parity on actual Lucy/bunny files stays unpinned; this pins the code paths they would take."""
+    from helpers import Case, pathological_scan, write_binary_ply
+    pts, tri = pathological_scan(28)
+    path = str(tmp_path / "scan.ply")
+    write_binary_ply(path, pts, tri)
+    p2, t2, _ = fa.read_mesh(path)
+    assert np.array_equal(t2, tri) and np.array_equal(p2, pts.astype(np.float32).astype(np.float64))
+    p2, t2 = fa.subdivide(p2, t2, 1)
+    case = Case(p2, t2, max(2, len(p2) // 400))            # <= 1024 faces per partition: the reference layout's limit
+    assert case.mesh.H - 3 * case.mesh.F > 100             # boundary half-edges
+    deg = np.diff(case.topo.rowptr)
+    assert (deg == 0).sum() > 10 and deg.max() >= 12       # vertices without faces; wide rows
+    st = case.ostats(ol.F64)
+    dt = stable_dt(st, case.model)
+    n0, c0 = smooth_ic(case.pts)
+    marr = case.model.as_array()
+    case.mesh.init_stats(fa.PREC_MIXED)
+    lay, dev = _ref_device(case)
+    dev.set_state(n0, c0)
+    dev.run(6, dt, case.model)
+    n_gpu, c_gpu = dev.get_state()
+    n_ref, c_ref = case.ostats(ol.MIXED).step(n0, c0, dt, 6, marr)
+    parity(n_gpu, c_gpu, n_ref, c_ref, TOL_REF)
+    case.mesh.init_stats(fa.PREC_F64)
+    n_ref, c_ref = st.step(n0, c0, dt, 23, marr)
+    for ksteps in (0, 5):
+        plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+        plan.set_state(n0, c0)
+        plan.run(23, dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F64, what="f64 k=%d" % ksteps)
+    n0r, c0r = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+    n_ref, c_ref = st.step(n0r, c0r, dt, 23, marr)
+    for ksteps in (0, 5):
+        plan = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps)
+        plan.set_state(n0r, c0r)
+        plan.run(23, dt, case.model)
+        n_gpu, c_gpu = plan.get_state()
+        parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32, tol_dev=DEV_SMOOTH_LARGE, what="f32 k=%d" % ksteps)

@@ -300,3 +300,45 @@ def test_bench_self_launch_verifies_at_two_ranks(steps, warmup):
     assert v["rel_l2_n_deviation"] <= 1e-5 and v["rel_l2_n"] <= 1e-5
     assert out["config"]["sustained"]["steps"] == 60 and out["config"]["sustained"]["value"] > 0
     assert out["roofline"]["vertices_per_launch"] == "rank 0's owned rows"
+
+
+@pytest.mark.gpu
+def test_bench_on_a_scan_file_with_pathologies(tmp_path):
+    """`bench.py --mesh FILE.ply --subdivide 1` (config 4 with a file instead of the synthetic stand-in): a scanner-style
+    binary PLY with open boundaries, unreferenced points and a non-manifold vertex goes through read -> upsample ->
+    partition -> fused fp32 plan, and the line verifies against the oracle"""
+    import json
+    from helpers import pathological_scan, write_binary_ply
+    pts, tri = pathological_scan(40)
+    path = str(tmp_path / "scan.ply")
+    write_binary_ply(path, pts, tri)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "4"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--mesh", path, "--subdivide", "1", "--steps", "20", "--warmup", "5",
+           "--sustained-steps", "0", "--no-cpu-baseline"]
+    res = subprocess.run(cmd, timeout=300, env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["data"] == "file scan.ply" and out["verify"]["ok"] and out["verify"]["steps"] == 25
+    assert out["config"]["mesh"]["valence_histogram"][0] > 10          # vertices without faces were kept
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_bench_config5_on_two_ranks(precision):
+    """BASELINE config 5 sharded (`bench.py --workload deform250k --gpus 2`, gloo rehearsal on one GPU): every rank
+    deforms and re-assembles the rows of its local vertices, ghost positions deform locally, the state is exchanged
+    every 4 iterations; the gathered owned rows are checked against the oracle re-assembling the deformed mesh every
+    iteration (fp32: the oracle's mixed-precision assembly, 2e-5; fp64: 1e-11)"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "4"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--workload", "deform250k",
+           "--steps", "9", "--warmup", "2", "--sustained-steps", "0", "--precision", precision]
+    res = subprocess.run(cmd, timeout=400, env=env, capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    v = out["verify"]
+    assert out["n_gpus"] == 2 and v["ok"] and v["steps"] == 11, v
+    assert max(v["rel_l2_n"], v["rel_l2_c"]) <= (2e-5 if precision == "f32" else 1e-11)
+    assert out["roofline"]["kernel"] == "assemble_step_sell_kernel"
