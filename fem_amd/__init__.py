@@ -532,6 +532,15 @@ class Plan:
         mp = C.byref(model) if model is not None else None
         _check(lib.fem_plan_run_imex(self.h, C.c_int(nsteps), C.c_double(dt), mp, C.c_int(cg_iterations), vp(stream or 0)))
 
+    def imex_tolerance(self, rel_tol):
+        """residual-based stop of the CG solves (0 = fixed iteration count)"""
+        _check(lib.fem_plan_imex_tolerance(self.h, C.c_double(rel_tol)))
+
+    def imex_iterations(self):
+        it = C.c_int()
+        _check(lib.fem_plan_imex_iterations(self.h, C.byref(it)))
+        return it.value
+
     def imex_residual(self):
         a, b = C.c_double(), C.c_double()
         _check(lib.fem_plan_imex_residual(self.h, C.byref(a), C.byref(b)))

@@ -126,6 +126,7 @@ struct fem_plan {
   double *maxedge = nullptr, *blockmax = nullptr;
   // semi-implicit stepping (FEM_PLAN_IMPLICIT): lumped mass and row sums of w per row; CG work vectors
   bool can_imex = false, imex_ready = false;
+  double imex_tol = 0;              // fem_plan_imex_tolerance: relative residual at which a solve stops (0: fixed iteration count)
   void *mass = nullptr, *wsum = nullptr, *ix_w = nullptr, *ix_r = nullptr, *ix_p = nullptr, *ix_q = nullptr;
   double *ix_partial = nullptr, *ix_sc = nullptr;
   void *coef = nullptr;            // float4 / double4 [entries]
@@ -269,15 +270,17 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
   typedef typename Vec<T>::t4 T4;
   const size_t V = p->V;
   const fem_uint Vdot = comm ? nOwn : p->V;
+  const double tol2 = p->imex_tol * p->imex_tol;      // 0: fixed iteration count
   auto reduce = [&](fem_uint nparts, int what) -> int {          // partial sums -> scalars (global ones on a shard)
     if (!comm) {
-      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nparts, p->ix_sc, what);
+      hipLaunchKernelGGL(imex_scalar_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nparts, p->ix_sc, what, tol2);
       return FEM_OK;
     }
-    hipLaunchKernelGGL(imex_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nparts, p->ix_sc + 12);
+    hipLaunchKernelGGL(imex_reduce_kernel, dim3(1), dim3(256), 0, st, (const double *)p->ix_partial, nparts, p->ix_sc + 12,
+                       (const double *)p->ix_sc, what);
     const int rc = comm->allreduce_sum(comm->ctx, (uint64_t)(p->ix_sc + 12), 2, (void *)st);
     if (rc != FEM_OK) return rc;
-    hipLaunchKernelGGL(imex_finish_kernel, dim3(1), dim3(64), 0, st, (const double *)(p->ix_sc + 12), p->ix_sc, what);
+    hipLaunchKernelGGL(imex_finish_kernel, dim3(1), dim3(64), 0, st, (const double *)(p->ix_sc + 12), p->ix_sc, what, tol2);
     return FEM_OK;
   };
   auto ghosts = [&](void *vec) -> int { return comm ? comm->exchange(comm->ctx, (uint64_t)vec, (void *)st) : FEM_OK; };
@@ -315,12 +318,12 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
     IMEX_TRY(ghosts(x));
     // r0 = M b - A b, p0 = r0 / diag, rz
     hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)x, (T2 *)p->ix_q, (T2 *)p->ix_r, (T2 *)p->ix_p,
-                       p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, Vdot, p->nslices, p->nblocks, dtDn, dtDc, 1, p->ix_partial);
+                       p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, Vdot, p->nslices, p->nblocks, dtDn, dtDc, 1, p->ix_partial, (const double *)p->ix_sc);
     IMEX_TRY(reduce(nbs, 0));
     IMEX_TRY(ghosts(p->ix_p));
     for (int it = 0; it < iters; it++) {
       hipLaunchKernelGGL(imex_apply_kernel<T>, dim3(nbs), dim3(256), 0, st, (const T2 *)p->ix_p, (T2 *)p->ix_q, (T2 *)nullptr, (T2 *)nullptr,
-                         p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, Vdot, p->nslices, p->nblocks, dtDn, dtDc, 0, p->ix_partial);
+                         p->slice_off.p, p->idx.p, (const T *)p->ix_w, mass, wsum, p->V, Vdot, p->nslices, p->nblocks, dtDn, dtDc, 0, p->ix_partial, (const double *)p->ix_sc);
       IMEX_TRY(reduce(nbs, 1));
       hipLaunchKernelGGL(imex_update_kernel<T>, dim3(nbv), dim3(256), 0, st, x, (T2 *)p->ix_r, (const T2 *)p->ix_p, (const T2 *)p->ix_q,
                          mass, wsum, p->V, Vdot, dtDn, dtDc, (const double *)p->ix_sc, p->ix_partial);
@@ -991,6 +994,21 @@ int fem_plan_pack_vector(fem_plan *p, uint64_t dev_vector, uint64_t dst_dev, voi
     hipLaunchKernelGGL(pack_halo_kernel<double2>, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double2 *)dev_vector,
                        p->send_idx.p, (double2 *)dst_dev, n);
   HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
+int fem_plan_imex_tolerance(fem_plan *p, double rel_tol) {
+  if (!p || !p->can_imex || !(rel_tol >= 0) || rel_tol >= 1) return fail(FEM_ERR_INVALID, "fem_plan_imex_tolerance: plan without FEM_PLAN_IMPLICIT, or tolerance outside [0, 1)");
+  p->imex_tol = rel_tol;
+  return FEM_OK;
+}
+
+int fem_plan_imex_iterations(fem_plan *p, int *iterations) {
+  if (!p || !p->ix_sc || !iterations) return fail(FEM_ERR_INVALID, "fem_plan_imex_iterations: no semi-implicit step has run");
+  double sc[16];
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(sc, p->ix_sc, sizeof sc, hipMemcpyDeviceToHost));
+  *iterations = (int)sc[11];
   return FEM_OK;
 }
 

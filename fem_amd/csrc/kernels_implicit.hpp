@@ -20,8 +20,9 @@ __global__ __launch_bounds__(256) void imex_apply_kernel(const typename Vec<T>::
                                                          const uint *__restrict__ slice_off, const uint *__restrict__ idx,
                                                          const T *__restrict__ wgt, const T *__restrict__ mass,
                                                          const T *__restrict__ wsum, uint V, uint Vdot, uint nslices, uint nblocks, T dtDn, T dtDc,
-                                                         int mode, double *__restrict__ partial) {
+                                                         int mode, double *__restrict__ partial, const double *__restrict__ sc) {
   typedef typename Vec<T>::t2 T2;
+  if (mode == 0 && sc[10] != 0.0) return;        // this solve has met its tolerance: the rest of its launches are no-ops
   const uint b = blockIdx.x, q8 = nblocks >> 3, r8 = nblocks & 7u, xcd = b & 7u;
   const uint lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (b >> 3);
   const uint slice = lb * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
@@ -82,10 +83,28 @@ __global__ __launch_bounds__(256) void imex_weights_kernel(const typename Vec<T>
 }
 
 // scalars sc[]: 0,1 rz   2,3 alpha   4,5 beta   6,7 r0z0 (first residual norms)   8,9 last rz
+//   10 "converged" (0 / 1)   11 iterations taken by the current solve
 //   what 0: rz = sum;  r0z0 = sum                        (after the mode-1 apply)
 //   what 1: alpha = rz / sum (sum = p.q)                  (after a mode-0 apply)
 //   what 2: beta = sum / rz;  rz = sum                    (after the update)
-__global__ __launch_bounds__(256) void imex_scalar_kernel(const double *__restrict__ partial, uint n, double *__restrict__ sc, int what) {
+// tol2 > 0 (fem_plan_imex_tolerance): once r.z <= tol2 * r0.z0 for both fields the solve is marked converged and every
+// later launch of it returns at once -- a residual-based stop inside a fixed launch sequence, no host synchronisation.
+__device__ __forceinline__ void imex_scalars(double s0, double s1, double *__restrict__ sc, int what, double tol2) {
+  if (what == 0) {
+    sc[0] = s0; sc[1] = s1; sc[6] = s0; sc[7] = s1; sc[8] = s0; sc[9] = s1;
+    sc[10] = (tol2 > 0 && s0 <= 0 && s1 <= 0) ? 1.0 : 0.0; sc[11] = 0.0;
+  } else if (what == 1) {
+    sc[2] = s0 > 0 ? sc[0] / s0 : 0.0; sc[3] = s1 > 0 ? sc[1] / s1 : 0.0;
+  } else {
+    sc[4] = sc[0] > 0 ? s0 / sc[0] : 0.0; sc[5] = sc[1] > 0 ? s1 / sc[1] : 0.0; sc[0] = s0; sc[1] = s1; sc[8] = s0; sc[9] = s1;
+    sc[11] += 1.0;
+    if (tol2 > 0 && s0 <= tol2 * sc[6] && s1 <= tol2 * sc[7]) sc[10] = 1.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void imex_scalar_kernel(const double *__restrict__ partial, uint n, double *__restrict__ sc, int what,
+                                                          double tol2) {
+  if (what != 0 && sc[10] != 0.0) return;
   __shared__ double sp[8];
   double d0 = 0, d1 = 0;
   for (uint i = threadIdx.x; i < n; i += 256) { d0 += partial[2 * (size_t)i]; d1 += partial[2 * (size_t)i + 1]; }
@@ -95,15 +114,15 @@ __global__ __launch_bounds__(256) void imex_scalar_kernel(const double *__restri
   __syncthreads();
   if (threadIdx.x == 0) {
     const double s0 = (sp[0] + sp[2]) + (sp[4] + sp[6]), s1 = (sp[1] + sp[3]) + (sp[5] + sp[7]);
-    if (what == 0) { sc[0] = s0; sc[1] = s1; sc[6] = s0; sc[7] = s1; sc[8] = s0; sc[9] = s1; }
-    else if (what == 1) { sc[2] = s0 > 0 ? sc[0] / s0 : 0.0; sc[3] = s1 > 0 ? sc[1] / s1 : 0.0; }
-    else { sc[4] = sc[0] > 0 ? s0 / sc[0] : 0.0; sc[5] = sc[1] > 0 ? s1 / sc[1] : 0.0; sc[0] = s0; sc[1] = s1; sc[8] = s0; sc[9] = s1; }
+    imex_scalars(s0, s1, sc, what, tol2);
   }
 }
 
 // The same in two halves for a sharded solve: the local sums (this rank's owned rows) go to loc[0..1], are summed over
 // the ranks by the caller's all-reduce, and imex_finish_kernel forms alpha / beta from the global sums on every rank.
-__global__ __launch_bounds__(256) void imex_reduce_kernel(const double *__restrict__ partial, uint n, double *__restrict__ loc) {
+__global__ __launch_bounds__(256) void imex_reduce_kernel(const double *__restrict__ partial, uint n, double *__restrict__ loc,
+                                                          const double *__restrict__ sc, int what) {
+  if (what != 0 && sc[10] != 0.0) return;
   __shared__ double sp[8];
   double d0 = 0, d1 = 0;
   for (uint i = threadIdx.x; i < n; i += 256) { d0 += partial[2 * (size_t)i]; d1 += partial[2 * (size_t)i + 1]; }
@@ -114,12 +133,12 @@ __global__ __launch_bounds__(256) void imex_reduce_kernel(const double *__restri
   if (threadIdx.x == 0) { loc[0] = (sp[0] + sp[2]) + (sp[4] + sp[6]); loc[1] = (sp[1] + sp[3]) + (sp[5] + sp[7]); }
 }
 
-__global__ void imex_finish_kernel(const double *__restrict__ loc, double *__restrict__ sc, int what) {
+// (a converged solve: the local sums are stale and so is their all-reduced sum, identically on every rank, and this
+//  kernel, like every other of the solve, returns at once)
+__global__ void imex_finish_kernel(const double *__restrict__ loc, double *__restrict__ sc, int what, double tol2) {
   if (threadIdx.x != 0) return;
-  const double s0 = loc[0], s1 = loc[1];
-  if (what == 0) { sc[0] = s0; sc[1] = s1; sc[6] = s0; sc[7] = s1; sc[8] = s0; sc[9] = s1; }
-  else if (what == 1) { sc[2] = s0 > 0 ? sc[0] / s0 : 0.0; sc[3] = s1 > 0 ? sc[1] / s1 : 0.0; }
-  else { sc[4] = sc[0] > 0 ? s0 / sc[0] : 0.0; sc[5] = sc[1] > 0 ? s1 / sc[1] : 0.0; sc[0] = s0; sc[1] = s1; sc[8] = s0; sc[9] = s1; }
+  if (what != 0 && sc[10] != 0.0) return;
+  imex_scalars(loc[0], loc[1], sc, what, tol2);
 }
 
 // x += alpha p;  r -= alpha q;  partials of r.(r/diag)
@@ -129,6 +148,7 @@ __global__ __launch_bounds__(256) void imex_update_kernel(typename Vec<T>::t2 *_
                                                           const T *__restrict__ mass, const T *__restrict__ wsum, uint V, uint Vdot, T dtDn, T dtDc,
                                                           const double *__restrict__ sc, double *__restrict__ partial) {
   typedef typename Vec<T>::t2 T2;
+  if (sc[10] != 0.0) return;
   const uint v = blockIdx.x * 256 + threadIdx.x;
   double d0 = 0, d1 = 0;
   if (v < V) {
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(256) void imex_direction_kernel(typename Vec<T>::t2
                                                              const T *__restrict__ mass, const T *__restrict__ wsum, uint V, T dtDn,
                                                              T dtDc, const double *__restrict__ sc) {
   const uint v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= V) return;
+  if (v >= V || sc[10] != 0.0) return;
   const T b0 = (T)sc[4], b1 = (T)sc[5], a = mass[v], ws = wsum[v];
   typename Vec<T>::t2 pv = p[v];
   const typename Vec<T>::t2 rv = r[v];

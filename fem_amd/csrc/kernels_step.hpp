@@ -313,6 +313,9 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
       if (t + TPB * q < rpad) xs_info[t + TPB * q] = xi[q];
   }
   if (PRO >= 1) loadGhostIds(0);
+  // X == 2: pin the id loads here.  Left to itself that build sinks them below the operator loads, next to the state
+  // gathers that use them, so the gathers wait behind the whole operator stream (s_waitcnt vmcnt(0) in front of them
+  // instead of vmcnt(32) in the X == 1 build): the "scheduling accident" that cost wide-row plans ~20 %.
 #pragma unroll
   for (int q = 0; q < R; q++) {
     const uint r = min(t + TPB * q, rpad - 1);         // rows in [rows, rpad) are zero padding
@@ -353,6 +356,12 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
       xs_coef[i] = tcoef[W * rpad + i];
       xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
     }
+  }
+  // (an IR pass moves them past the guard of the staging loop below, the only place that uses them: an opaque use in
+  //  front of that guard, behind the operator loads, keeps them where they were written -- first)
+  if constexpr (X == 2 && PRO >= 1) {
+#pragma unroll
+    for (int u = 0; u < SU; u++) asm volatile("" : "+v"(gi[u]));
   }
   for (uint i0 = 0; i0 < mk; i0 += SU * TPB) {
     T2 sv[SU];

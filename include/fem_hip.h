@@ -341,6 +341,13 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
  * preconditioned residual norm of the last solve relative to its first one (synchronises). */
 int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
 int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c);
+/* Residual-based stop (default 0 = every solve takes exactly cg_iterations): with rel_tol > 0 a solve ends as soon as
+ * the preconditioned residual of BOTH fields is <= rel_tol times its first one; cg_iterations is then the upper bound.
+ * The launch sequence stays fixed and free of host synchronisation: the kernels of a finished solve return at once
+ * (a device flag), on every rank of a sharded solve alike (the sums are global).  fem_plan_imex_iterations: iterations
+ * the last solve took (synchronises). */
+int fem_plan_imex_tolerance(fem_plan *p, double rel_tol);
+int fem_plan_imex_iterations(fem_plan *p, int *iterations);
 /* The same steps on a shard's plan (fem_plan_create_ex(..., shard, ..., ksteps = 0, FEM_PLAN_IMPLICIT); one ghost ring is
  * enough): the conjugate-gradient iteration distributed over the ranks.  The library runs the kernels; the caller
  * supplies the two communication steps as callbacks, both asynchronous on `stream`:

@@ -57,6 +57,17 @@ def test_imex_matches_scipy(make, nparts, factor):
     plan32.run_imex(5, dt, case.model, cg_iterations=25)
     n32, c32 = plan32.get_state()
     parity(n32, c32, n_ref, c_ref, 1e-5)
+    # residual-based stop: same answer to the tolerance asked for, in fewer iterations than the bound
+    plan.set_state(n0, c0)
+    plan.imex_tolerance(1e-10)
+    plan.run_imex(5, dt, case.model, cg_iterations=200)
+    nt, ct = plan.get_state()
+    its = plan.imex_iterations()
+    assert 1 <= its < 200 and max(plan.imex_residual()) <= 1e-10, (its, plan.imex_residual())
+    parity(nt, ct, n_ref, c_ref, 1e-9)
+    plan.imex_tolerance(0.0)
+    plan.run_imex(1, dt, case.model, cg_iterations=7)
+    assert plan.imex_iterations() == 7
 
 
 def test_imex_is_stable_where_explicit_is_not():

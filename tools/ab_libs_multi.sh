@@ -4,7 +4,7 @@
 set -o pipefail
 cp fem_amd/lib/libfem_hip.so /tmp/libfem_hip.keep
 trap 'cp /tmp/libfem_hip.keep fem_amd/lib/libfem_hip.so' EXIT
-b() { timeout -k 10 250 python bench.py --no-cpu-baseline --no-verify --sustained-steps 0 "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f G' % (d['value']/1e9))"; }
+b() { timeout -k 10 250 python bench.py --no-cpu-baseline --no-verify --no-variants --sustained-steps 0 "$@" 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%.1f G' % (d['value']/1e9))"; }
 for round in $(seq 1 ${2:-2}); do
   for tag in $1; do
     cp build_ab/libfem_hip_$tag.so fem_amd/lib/libfem_hip.so

@@ -6,8 +6,8 @@ TAG=$1; WL=$2; shift 2
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/$TAG
 rm -rf $OUT && mkdir -p $OUT
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq1 -- python3 bench.py --workload $WL --steps 40 --no-cpu-baseline --no-verify --sustained-steps 0 "$@" > $OUT/sq1.log 2>&1 || exit 3
-timeout -s KILL 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/sq2 -- python3 bench.py --workload $WL --steps 40 --no-cpu-baseline --no-verify --sustained-steps 0 "$@" > $OUT/sq2.log 2>&1 || exit 4
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/sq1 -- python3 bench.py --workload $WL --steps 40 --no-cpu-baseline --no-verify --no-variants --sustained-steps 0 "$@" > $OUT/sq1.log 2>&1 || exit 3
+timeout -s KILL 300 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/sq2 -- python3 bench.py --workload $WL --steps 40 --no-cpu-baseline --no-verify --no-variants --sustained-steps 0 "$@" > $OUT/sq2.log 2>&1 || exit 4
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
