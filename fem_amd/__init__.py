@@ -243,13 +243,18 @@ class Mesh:
         return out
 
     def partition_vertices(self, n, method="rcb"):
-        """vertex -> part id; method "rcb" (coordinate bisection), "graph" (graph bisection) or "multilevel" (multilevel k-way
-        on the dual graph, the METIS_PartMeshDual stage)"""
+        """vertex -> part id; method "rcb" (coordinate bisection), "graph" (graph bisection), "auto" (rcb unless its cut says
+        the coordinates mislead, then graph) or "multilevel" (multilevel k-way on the dual graph, the METIS_PartMeshDual stage)"""
         npart = np.empty(self.V, np.int64)
         if method == "multilevel":
             cut = C.c_int64()
             _check(lib.fem_partition_vertices_multilevel(self.h, C.c_int(n), _ptr(npart, i64p), None, C.byref(cut)))
             self.last_dual_cut = cut.value
+            return npart
+        if method == "auto":
+            chosen = C.c_int()
+            _check(lib.fem_partition_vertices_auto(self.h, C.c_int(n), _ptr(npart, i64p), C.byref(chosen)))
+            self.last_partitioner = "graph" if chosen.value == 1 else "rcb"
             return npart
         fn = {"rcb": lib.fem_partition_vertices, "graph": lib.fem_partition_vertices_graph}[method]
         _check(fn(self.h, C.c_int(n), _ptr(npart, i64p)))

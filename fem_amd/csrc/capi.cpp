@@ -183,6 +183,14 @@ int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart) {
   });
 }
 
+int fem_partition_vertices_auto(const fem_mesh *m, int n, int64_t *npart, int *chosen) {
+  return fem::guarded("fem_partition_vertices_auto", [&]() -> int {
+  if (!m || !npart) return fail(FEM_ERR_INVALID, "fem_partition_vertices_auto: null");
+  int rc = fem::partitionVerticesAuto(m->mesh, n, npart, chosen);
+  return rc == FEM_OK ? rc : fail(rc, "fem_partition_vertices_auto: need 1 <= n <= V");
+  });
+}
+
 int fem_partition_vertices_multilevel(const fem_mesh *m, int n, int64_t *npart, int64_t *epart, int64_t *dual_cut) {
   return fem::guarded("fem_partition_vertices_multilevel", [&]() -> int {
   if (!m || !npart) return fail(FEM_ERR_INVALID, "fem_partition_vertices_multilevel: null");

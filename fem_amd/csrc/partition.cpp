@@ -6,6 +6,7 @@
 // Stages R1-R3 (face buckets, stable counting-sort renumbering, mesh rebuild)
 // keep the reference's exact rules.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <thread>
 
@@ -179,6 +180,38 @@ int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart) {
   r.ids.resize((size_t)V);
   for (int64_t i = 0; i < V; i++) r.ids[i] = (uint32_t)i;
   r.run(0, (size_t)V, 0, n);
+  return FEM_OK;
+}
+
+// Stage R0 chosen by what the partition costs the fused kernel.  Coordinate bisection first (cheap, exactly equal
+// parts, the lowest ring redundancy on surfaces whose coordinates tell the truth); its edge cut is then priced against
+// the perimeter a compact part has: cut edges / (parts x sqrt(rows per part)) is 4.0-4.4 for compact parts on the
+// spheres and the scanned-like mesh, and 8.9 on a rolled sheet whose layers lie closer in space than its edges are long
+// (parts there are stacks of disconnected pieces: ring redundancy 3.26 against 1.88, profiles/r03_partition_quality.jsonl).
+// Above 6 the coordinate-free graph bisection (same balance, same hierarchical numbering) replaces it when its cut is lower.
+int partitionVerticesAuto(const SimpleTriMesh &m, int n, int64_t *npart, int *chosen) {
+  if (chosen) *chosen = 0;
+  int rc = partitionVertices(m, n, npart);
+  if (rc != FEM_OK || n < 2 || m.H == 0) return rc;
+  const int64_t F = m.n_faces(), V = m.n_vertices();
+  auto cutOf = [&](const int64_t *part) {
+    int64_t c = 0;
+    for (int64_t f = 0; f < F; f++) {
+      const int64_t a = part[m.faces[3 * f]], b = part[m.faces[3 * f + 1]], d = part[m.faces[3 * f + 2]];
+      c += (a != b) + (b != d) + (d != a);
+    }
+    return c;                                   // interior edges counted twice, boundary edges once: a proxy is enough
+  };
+  const int64_t cutRcb = cutOf(npart);
+  const double q = 0.5 * (double)cutRcb / ((double)n * std::sqrt((double)V / (double)n));
+  if (q <= 6.0) return FEM_OK;
+  std::vector<int64_t> alt((size_t)V);
+  rc = partitionVerticesGraph(m, n, alt.data());
+  if (rc != FEM_OK) return FEM_OK;              // keep the coordinate split
+  if (cutOf(alt.data()) < cutRcb) {
+    std::copy(alt.begin(), alt.end(), npart);
+    if (chosen) *chosen = 1;
+  }
   return FEM_OK;
 }
 

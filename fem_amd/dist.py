@@ -12,9 +12,10 @@ _PROFILES = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file_
 
 
 def _partition(mesh, nparts):
-    """R0 stage by FEM_PARTITIONER: rcb (default; exactly equal parts, lowest cut on the surfaces measured), graph,
-    multilevel (METIS_PartMeshDual-style: multilevel k-way on the dual graph)"""
-    return mesh.partition(nparts, method=os.environ.get("FEM_PARTITIONER", "rcb"))
+    """R0 stage by FEM_PARTITIONER: auto (default: rcb -- exactly equal parts, lowest cut and ring redundancy on the
+    surfaces measured -- unless its cut says the coordinates mislead, then graph), rcb, graph, multilevel
+    (METIS_PartMeshDual-style: multilevel k-way on the dual graph)"""
+    return mesh.partition(nparts, method=os.environ.get("FEM_PARTITIONER", "auto"))
 
 
 def _time_step(om, model, rule):

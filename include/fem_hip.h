@@ -161,6 +161,14 @@ int fem_partition_vertices(const fem_mesh *m, int n, int64_t *npart);
  * at most one), same hierarchical numbering, deterministic.  For surfaces where a coordinate
  * split makes disconnected parts (folds, thin sheets); feed the result to fem_partition_apply. */
 int fem_partition_vertices_graph(const fem_mesh *m, int n, int64_t *npart);
+/* The two above under one call (the drivers' default, FEM_PARTITIONER=auto): coordinate bisection, kept unless its
+ * edge cut is far above what compact parts have (cut edges / (parts x sqrt(rows per part)) > 6: the sign of a surface
+ * whose coordinates mislead -- folds, rolled or stacked sheets -- where its parts fall apart into pieces and the fused
+ * kernel's ring redundancy nearly doubles); then graph bisection, if that cuts fewer edges.  *chosen (optional):
+ * 0 = coordinate, 1 = graph.  Both are recursive bisections, so the part numbering is hierarchical either way: a rank's
+ * contiguous range of parts (fem_shard_create) is a subtree, i.e. the split across GPUs is the top of the same recursion
+ * that makes the tile-sized parts, with part sizes differing by at most one row. */
+int fem_partition_vertices_auto(const fem_mesh *m, int n, int64_t *npart, int *chosen);
 /* Same stage the way METIS_PartMeshDual does it (partitioning_common.cpp:51-58, ncommon = 2): multilevel k-way
  * partition of the DUAL graph (elements adjacent across an edge) -- heavy-edge-matching coarsening, weighted
  * coordinate bisection of the coarsest graph, greedy k-way boundary refinement at every level, part weights within

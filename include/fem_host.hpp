@@ -95,6 +95,7 @@ int partition(const SimpleTriMesh &originalMesh, SimpleTriMesh *orderedMesh, uin
 // pieces of the above (partitioning_common.cpp:32-176)
 int partitionVertices(const SimpleTriMesh &m, int n, int64_t *npart);          // coordinate bisection
 int partitionVerticesGraph(const SimpleTriMesh &m, int n, int64_t *npart);     // graph bisection (needs topology)
+int partitionVerticesAuto(const SimpleTriMesh &m, int n, int64_t *npart, int *chosen = nullptr);   // coordinate bisection unless its cut says the coordinates mislead; then graph bisection
 // multilevel k-way on the dual graph (the METIS_PartMeshDual stage, partitioning_common.cpp:51-58; needs topology);
 // epart (optional, [F]) receives the element partition the node partition was induced from
 int partitionVerticesMultilevel(const SimpleTriMesh &m, int n, int64_t *npart, int64_t *epart = nullptr);

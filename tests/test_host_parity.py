@@ -467,3 +467,41 @@ def test_multilevel_dual_graph_partition():
         assert part_ml.node_parts[-1] == mesh.V and np.array_equal(np.diff(part_ml.node_parts.astype(np.int64)), sizes)
     with pytest.raises(fa.FemError):
         fa.Mesh(*fa.make_icosphere(2, 0.1)).partition_vertices(100000, "multilevel")
+
+
+def rolled_sheet(nx=600, ny=120, h=0.1, gap=0.35):
+    """a sheet rolled into a spiral whose layers lie closer in space (gap) than a part is wide: near in coordinates,
+    far on the surface -- the kind of surface a coordinate split cuts into stacks of disconnected pieces"""
+    u = np.arange(nx) * h
+    b = gap / (2 * np.pi)
+    theta = np.sqrt(2 * (u + 5.0) / b)
+    r = b * theta
+    x, z = r * np.cos(theta), r * np.sin(theta)
+    pts = np.stack([np.repeat(x[:, None], ny, 1).ravel(), np.repeat((np.arange(ny) * h)[None, :], nx, 0).ravel(),
+                    np.repeat(z[:, None], ny, 1).ravel()], 1)
+    idx = np.arange(nx * ny).reshape(nx, ny)
+    a, b_, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    return pts, np.concatenate([np.stack([a, b_, c], 1), np.stack([a, c, d], 1)]).astype(np.uint32)
+
+
+def test_auto_partitioner_keeps_rcb_unless_coordinates_mislead():
+    """stage R0 as the drivers run it (FEM_PARTITIONER=auto): identical to the coordinate bisection on the sphere and on
+    the irregular scanned-like mesh; on a rolled sheet it switches to the coordinate-free graph bisection, whose parts
+    are connected (half the edge cut), with the same exact balance -- and the R1-R3 contract holds on its output"""
+    for pts, tri in (fa.make_icosphere(48, 0.1), fa.make_scanned_like(32, 0.1, seed=3)):
+        m = fa.Mesh(pts, tri)
+        n = m.V // 400
+        assert np.array_equal(m.partition_vertices(n, "auto"), m.partition_vertices(n, "rcb")) and m.last_partitioner == "rcb"
+    pts, tri = rolled_sheet()
+    m = fa.Mesh(pts, tri)
+    n = m.V // 600
+    auto = m.partition_vertices(n, "auto")
+    assert m.last_partitioner == "graph" and np.array_equal(auto, m.partition_vertices(n, "graph"))
+    sizes = np.bincount(auto, minlength=n)
+    assert sizes.max() - sizes.min() <= 1
+    cut_auto, cut_rcb = m.partition(n, npart=auto).cut, m.partition(n, method="rcb").cut
+    assert cut_auto < 0.6 * cut_rcb, (cut_auto, cut_rcb)
+    part = m.partition(n, method="auto")
+    pv, pf, nparts, eparts, pts_o, tri_o = ol.partition_apply(m.V, pts, tri, auto, n)
+    assert np.array_equal(part.perm_v, pv) and np.array_equal(part.perm_f, pf) and np.array_equal(part.node_parts, nparts)
+    assert np.array_equal(part.element_parts, eparts) and np.array_equal(part.ordered.tri, tri_o)
