@@ -238,7 +238,9 @@ def oracle_reference(runner, total_steps, precision):
     topo = ol.Topology(om.V, om.tri)
     st = ol.Stats(topo, om.points, ol.F64)
     n0, c0 = _rounded_ic(runner, om.V, precision)
-    threads = ol.set_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1))
+    # (a launcher may have set OMP_NUM_THREADS=1 for every rank; the check runs on rank 0 alone, after the timed region,
+    #  while the other ranks wait: it may use the host's cores)
+    threads = ol.set_threads(max(int(os.environ.get("OMP_NUM_THREADS", "0") or 0), min(16, os.cpu_count() or 1)))
     n_ref, c_ref = st.step(n0, c0, runner.dt, total_steps, runner.model.as_array())
     ol.set_threads(1)
     return {"n": n_ref, "c": c_ref, "n0": n0, "steps": total_steps, "ic_precision": precision,
