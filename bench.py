@@ -564,8 +564,10 @@ def main():
                            " STAGED THROUGH THE HOST over gloo (RCCL did not come up: %s)" % runner.fallback_reason)},
             "roofline": {"bound": "hbm", "kernel": runner.kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": ("recorded earlier for exactly this configuration (%s), not measured by this run: %s"
-                                            % (runner.traffic_key(), traffic_source)) if traffic else None,
+                         "traffic_source": ("recorded earlier for exactly this configuration (%s) and kernel build (%s), not measured "
+                                            "by this run: %s" % (runner.traffic_key(), fa.kernel_build(), traffic_source)) if traffic
+                         else traffic_source,
+                         "traffic_key": runner.traffic_key(), "kernel_build": fa.kernel_build(),
                          "traffic_rate": traffic / (kernel_ms * 1e-3) / 1e9 if traffic else None,
                          "traffic_frac": traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                          "alg_bytes_per_vertex_step": None if deform else ALG_BYTES_PER_VERTEX_STEP,

@@ -52,6 +52,7 @@ class FemError(RuntimeError):
 
 
 lib.fem_error_string.restype = C.c_char_p
+lib.fem_kernel_build.restype = C.c_char_p
 lib.fem_error_detail.restype = C.c_char_p
 lib.fem_plan_operator_bytes.restype = C.c_uint64
 lib.fem_plan_operator_bytes.argtypes = [vp]
@@ -79,6 +80,11 @@ def _check(rc):
 
 def _ptr(a, t):
     return a.ctypes.data_as(t)
+
+
+def kernel_build():
+    """digest of the device sources the loaded library was built from (fem_kernel_build)"""
+    return lib.fem_kernel_build().decode()
 
 
 def default_model():

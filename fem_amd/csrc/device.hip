@@ -344,6 +344,11 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
 
 extern "C" {
 
+#ifndef FEM_KERNEL_BUILD
+#define FEM_KERNEL_BUILD "unknown"
+#endif
+const char *fem_kernel_build(void) { return FEM_KERNEL_BUILD; }
+
 int fem_last_error(void) { return fem::g_last_error; }
 const char *fem_error_detail(void) { return fem::g_error_detail.c_str(); }
 

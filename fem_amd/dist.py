@@ -67,18 +67,25 @@ class SingleRun:
                                               ti["rows_per_thread"], self.part.n, ":rec12" if self.plan.operator_format() == 1 else "")
 
     def measured_traffic(self):
-        """(HBM bytes per launch, source tag) from the rocprofv3 PMC passes committed under profiles/ --
-        recorded on an earlier run of exactly this configuration (traffic_key), not measured by this
-        process; (None, None) if no pass was recorded for it"""
-        path = os.path.join(_PROFILES, "traffic.json")
-        if not os.path.exists(path):
-            return None, None
-        with open(path) as f:
-            rec = json.load(f)
-        hit = rec.get(self.traffic_key())
-        if not isinstance(hit, dict):
-            return None, None
-        return hit.get("hbm_bytes_per_launch"), hit.get("source")
+        return _recorded_traffic(self.traffic_key())
+
+
+def _recorded_traffic(key):
+    """(HBM bytes per launch, source tag) from the rocprofv3 PMC passes committed under profiles/ -- recorded on an earlier
+    run of exactly this configuration (traffic_key) AND this kernel build (fem_kernel_build: a digest of the device
+    sources), not measured by this process; (None, reason) when no pass was recorded for it or the kernels have
+    changed since"""
+    path = os.path.join(_PROFILES, "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        rec = json.load(f)
+    hit = rec.get(key)
+    if not isinstance(hit, dict):
+        return None, None
+    if hit.get("kernel_build") != fa.kernel_build():
+        return None, "recorded for kernel build %s (%s); this library is %s" % (hit.get("kernel_build"), hit.get("source"), fa.kernel_build())
+    return hit.get("hbm_bytes_per_launch"), hit.get("source")
 
 
 class DeformRun:
@@ -126,12 +133,7 @@ class DeformRun:
         return "%s:%s:%d" % (self.kernel_name, self.precision, self.V)
 
     def measured_traffic(self):
-        path = os.path.join(_PROFILES, "traffic.json")
-        if not os.path.exists(path):
-            return None, None
-        with open(path) as f:
-            hit = json.load(f).get(self.traffic_key())
-        return (hit.get("hbm_bytes_per_launch"), hit.get("source")) if isinstance(hit, dict) else (None, None)
+        return _recorded_traffic(self.traffic_key())
 
 
 class ShardedDeformRun:

@@ -44,6 +44,9 @@ typedef enum {
 
 void fem_default_model(fem_model *m);
 const char *fem_error_string(int status);
+/* digest of the device sources (kernels_*.hpp, device.hip) and code-shaping flags this library was built from: measured
+ * per-launch figures recorded under profiles/ (HBM traffic from counter passes) are tied to it */
+const char *fem_kernel_build(void);
 /* status of the last failing call on this thread (the `void step` shim has no
  * other way to report one) and the HIP error text that came with it */
 int fem_last_error(void);

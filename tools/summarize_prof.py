@@ -55,7 +55,10 @@ if len(sys.argv) > 5:
     kern = key.split(":")[0]
     tpath = os.path.join(out, "traffic.json")
     t = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    sys.path.insert(0, root)
+    import fem_amd as fa          # the library the passes were run on travels with the tree: its digest ties the figure to the kernels
     for k, v in summary.items():
         if kern in k and "hbm_bytes_per_launch" in v:
-            t[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "source": "profiles/%s_pmc.json" % tag}
+            t[key] = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"], "source": "profiles/%s_pmc.json" % tag,
+                      "kernel_build": fa.kernel_build()}
     json.dump(t, open(tpath, "w"), indent=1)
