@@ -395,6 +395,10 @@ def main():
     # (the library gives regular meshes the 2048-row register tile; meshes with rows wider than 6 entries and
     # plans below 1.5M rows -- kLargeMeshRows in device.hip, per rank -- get the 1536-row one)
     small = scanned or V_total // world < 1500000
+    if small and not scanned and world == 1 and args.precision == "f32" and 192 <= V_total // 975 <= 4096:
+        # ... except whole meshes of 192..4096 such tiles: fem_plan_run runs those in persistent launches (device.hip:
+        # persistRule), which do not need many small tiles to fill the workgroup slots
+        small = False
     if args.fuse < 0:
         args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if scanned else ("6" if small else "7")))
     tile_n0 = int(os.environ.get("FEM_TILE_N0", ({4: "950", 5: "820" if scanned else "880", 6: "760", 7: "650"} if small else

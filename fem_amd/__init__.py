@@ -493,13 +493,20 @@ class Plan:
         _check(lib.fem_plan_tile_info(self.h, C.byref(k), C.byref(nt), C.byref(ml), C.byref(rows), C.byref(thr),
                                       C.byref(rpt)))
         return dict(ksteps=k.value, ntiles=nt.value, max_local=ml.value, rows_loaded=rows.value,
-                    threads=thr.value, rows_per_thread=rpt.value,
+                    threads=thr.value, rows_per_thread=rpt.value, groups_per_launch=max(1, self.persist_groups()),
                     operator_records="12-byte (fp32 weight + 3 x 21-bit gradient coefficients, per-row scale)"
                     if self.operator_format() == 1 else "4 scalars")
 
     def pack_halo(self, dst_ptr, stream=None, which=0):
         """which = 0: from the current state buffer, 1: from the next one (see launch_tiles)"""
         _check(lib.fem_plan_pack_halo_from(self.h, which, dst_ptr, vp(stream or 0)))
+
+    def persist_groups(self):
+        """groups of ksteps steps one launch of run() may cover: 0 = one launch per group (tile_step_kernel), n > 0 = up
+        to n groups per launch of tile_step_persist_kernel (fem_plan_persist_groups)"""
+        g = C.c_int()
+        _check(lib.fem_plan_persist_groups(self.h, C.byref(g)))
+        return g.value
 
     def tile_classes(self):
         """(interior, boundary, ghost) tile counts; the tiles are ordered in that sequence"""

@@ -104,6 +104,10 @@ struct fem_plan {
   DevBuf<fem_uint> slice_off, idx, send_idx;
   // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
   int ksteps = 0, tcfg = 0;
+  // tile_step_persist_kernel: up to `persist` groups of k steps per launch (0: one launch per group; FEM_TILE_PERSIST,
+  // else by tile count: persistRule); its control words, the per-tile "groups finished" flags, the tiles each tile waits for
+  int persist = -1, persist_deps = 1, persist_grid = 0;
+  DevBuf<fem_uint> pctl, pdepOff, pdep;
   int device = -1;                  // ordinal of the GPU that was current when the plan was created (owns every buffer)
   int prologue = -1, sell_nt = -1;   // FEM_TILE_PROLOGUE / FEM_SELL_NT as read when the plan was created (-1: by operator size)
   fem_uint ntiles = 0, maxLocal = 0, maxExtra = 0;
@@ -254,6 +258,54 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
   hipLaunchKernelGGL(kern, dim3(count), dim3(TPB), lds, stream, (const T2 *)src, (T2 *)dst, p->tmeta.p,
                      p->tghost.p, p->tidx2.p, (const T4 *)p->tcoef, p->txinfo.p, first, count, p->maxLocal, p->maxExtra,
                      nsteps, m);
+  return hipSuccess;
+}
+
+// `groups` groups of up to ksteps steps in ONE launch of a fixed grid of workgroups that draw (group, tile) items from a
+// ticket and hand tiles over through per-tile flags (kernels_step.hpp): no chip-wide drain between groups.  Packed fp32
+// plans on the two default register tiles.  Same-session A/B against one launch per group (sphere, 975-row tiles, k = 7,
+// bit-identical states): 263 tiles +7 %, 1 056 tiles +17..22 % (290 -> 340 G DOF-it/s at 10 groups, 350 at 50),
+// 4 215 tiles +-0, 16 848 tiles -7 % (the per-item ticket / poll / publish chain costs more than the drain of a launch
+// that lasts 33 tile lifetimes), 2 tiles -25 %.  Hence the rule: plans of 192..4096 tiles, 32 groups per launch.
+constexpr int kPersistGroups = 32;
+constexpr fem_uint kPersistMinTiles = 192, kPersistMaxTiles = 4096;
+static int persistRule(fem_uint ntiles) { return ntiles >= kPersistMinTiles && ntiles <= kPersistMaxTiles ? kPersistGroups : 0; }
+
+constexpr size_t kPersistCtl = 144;      // eight tickets on lines of their own, the give-up word at [128]; the flags follow
+template <int C>
+static hipError_t launchTilePersist(fem_plan *p, void *buf0, void *buf1, int ksteps, int lastSteps, fem_uint groups,
+                                    const ModelT<float> &m, hipStream_t stream) {
+  constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r, MINW = kTileCfgs[C].minw;
+  const int pro = p->prologue >= 0 ? p->prologue : (p->tile_bytes > (256ull << 20) ? 3 : 1);
+  auto kern = p->maxExtra ? (pro >= 2 ? tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 2, 3, 1> : tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 2, 1, 1>)
+                          : (pro >= 2 ? tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 3, 1> : tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 1, 1>);
+  // FEM_TILE_PERSIST_COH (rate probes only; the results are wrong): 0 plain state accesses, 2 sc1 loads only, 3 sc1 stores only
+  static const int cm = getenv("FEM_TILE_PERSIST_COH") ? atoi(getenv("FEM_TILE_PERSIST_COH")) : 1;
+  if (!p->maxExtra && cm != 1) {
+    kern = cm == 0 ? (pro >= 2 ? tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 3, 1, 0> : tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 1, 1, 0>)
+         : cm == 2 ? (pro >= 2 ? tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 3, 1, 2> : tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 1, 1, 2>)
+                   : (pro >= 2 ? tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 3, 1, 3> : tile_step_persist_kernel<float, TPB, R, kTileW, MINW, 1, 1, 1, 3>);
+  }
+  size_t lds = 2 * (size_t)p->maxLocal * sizeof(float2) + (size_t)p->maxExtra * (sizeof(float4) + 4) +
+               (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
+  lds = (lds + 15) & ~(size_t)15;
+  const fem_uint ldsItem = (fem_uint)lds;
+  lds += 16;
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  // control words (ticket, abort) and flags start at zero for every launch
+  hipError_t e = hipMemsetAsync(p->pctl.p, 0, sizeof(fem_uint) * (kPersistCtl + (size_t)p->ntiles), stream);
+  if (e != hipSuccess) return e;
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  // at least one workgroup for each of the eight tile ranges
+  const fem_uint grid = (fem_uint)((std::max<uint64_t>(8, std::min<uint64_t>((uint64_t)p->ntiles * groups, p->persist_grid > 0 ? (uint64_t)p->persist_grid : 2ull * (uint64_t)cus)) + 7) & ~7ull);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(TPB), lds, stream, (float2 *)buf0, (float2 *)buf1, p->tmeta.p, p->tghost.p, p->tidx2.p,
+                     (const float4 *)p->tcoef, p->txinfo.p, 0u, p->ntiles, p->maxLocal, p->maxExtra, ksteps, lastSteps, groups, m,
+                     p->pctl.p, p->pctl.p + kPersistCtl, p->pdepOff.p, p->pdep.p, p->persist_deps, ldsItem);
   return hipSuccess;
 }
 
@@ -522,6 +574,7 @@ void fem_plan_destroy(fem_plan *p) {
   if (!p) return;
   p->slice_off.release(); p->idx.release(); p->send_idx.release();
   p->tmeta.release(); p->tghost.release(); p->tidx2.release(); p->txinfo.release();
+  p->pctl.release(); p->pdepOff.release(); p->pdep.release();
   p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release(); p->rowg.release();
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   for (void *q : {p->mass, p->wsum, p->ix_w, p->ix_r, p->ix_p, p->ix_q, (void *)p->ix_partial, (void *)p->ix_sc}) if (q) (void)hipFree(q);
@@ -572,8 +625,16 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     // per CU only fit with the 3-row tile
     bool wideRows = false;
     for (fem::uint r = 0; r < op.V && !wideRows; r++) wideRows = op.rowptr[r + 1] - op.rowptr[r] > kTileW;
-    // (small meshes: the 3-row tile too -- more, smaller tiles fill the 512 workgroup slots better)
-    tcfg = cfgEnv ? atoi(cfgEnv) : (wideRows || op.V < kLargeMeshRows ? kDefaultTileCfgWide : kDefaultTileCfg);
+    // (small meshes: the 3-row tile too -- more, smaller tiles fill the 512 workgroup slots better -- unless the caller
+    //  has cut partitions for the 4-row tile, > 800 rows on average, and fem_plan_run will hand the tiles over inside
+    //  persistent launches, which fill the slots whatever the tile count: sphere1m 313 G against 300 G with 3-row tiles)
+    const fem::uint nOwnedParts = (fem::uint)ranges.size() - (fem::uint)((op.V - (own_e - own_b) + 511) / 512);
+    const bool bigParts = nOwnedParts > 0 && (own_e - own_b) / nOwnedParts > 800;
+    const char *perEnv = getenv("FEM_TILE_PERSIST"), *pk0 = getenv("FEM_TILE_PACKED");
+    const bool persistLikely = !shard && precision == FEM_PREC_F32 && !(flags & FEM_PLAN_DEVICE_ASSEMBLY) && !(pk0 && !strcmp(pk0, "0")) &&
+                               (perEnv ? atoi(perEnv) > 0 : persistRule((own_e - own_b + 974) / 975) > 0);
+    tcfg = cfgEnv ? atoi(cfgEnv)
+                  : (wideRows || (op.V < kLargeMeshRows && !(bigParts && persistLikely)) ? kDefaultTileCfgWide : kDefaultTileCfg);
     if (tcfg < 0 || tcfg >= kNumTileCfgs) return fail(FEM_ERR_INVALID, "FEM_TILE_CONFIG out of range");
     rc = fem::packTileLayout(op, ranges, ksteps, kTileCfgs[tcfg].tpb, kTileCfgs[tcfg].r, kTileW,
                              precision == FEM_PREC_F32 ? kTileMaxLocal : kTileMaxLocal * 3 / 4,
@@ -617,6 +678,9 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   p->precision = precision; p->V = op.V;
   if (const char *e = getenv("FEM_TILE_PROLOGUE")) p->prologue = std::min(3, std::max(0, atoi(e)));
   if (const char *e = getenv("FEM_SELL_NT")) p->sell_nt = atoi(e) != 0;
+  if (const char *e = getenv("FEM_TILE_PERSIST")) p->persist = std::max(0, atoi(e));      // 0 off, n: n groups per launch, whatever the size
+  if (const char *e = getenv("FEM_TILE_PERSIST_DEPS")) p->persist_deps = atoi(e) != 0;
+  if (const char *e = getenv("FEM_TILE_PERSIST_GRID")) p->persist_grid = std::max(0, atoi(e));
   const size_t sb = precision == FEM_PREC_F32 ? sizeof(float) : sizeof(double);
   hipError_t e = hipSuccess;
   auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
@@ -635,6 +699,36 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     p->maxLocal = (TL.maxLocal + 1) & ~1u; p->maxExtra = TL.maxExtra; p->tile_entries = TL.coef.size() / 4;
     p->tile_bytes = (uint64_t)(TL.coef.size() / 4) * (4 * sb + 2) + (uint64_t)TL.ghost.size() * 4 + (uint64_t)TL.meta.size() * 4 +
                     (uint64_t)TL.xinfo.size() * 4;
+    if (p->persist < 0) p->persist = persistRule(TL.ntiles);
+    if (p->persist > 0) {
+      // tiles each tile waits for: the owners of its ring rows, and itself (another workgroup may run its next group)
+      std::vector<fem_uint> owner(op.V, 0u), depOff(TL.ntiles + 1, 0u), dep;
+      for (fem_uint t = 0; t < TL.ntiles; t++) {
+        const fem_uint *mt = &TL.meta[16 * (size_t)t];
+        for (fem_uint i = 0; i < mt[5]; i++) owner[mt[0] + i] = t;
+      }
+      // (made symmetric: a tile whose rings are cut off at a shard's edge may not reach a tile that reaches it)
+      std::vector<std::vector<fem_uint>> nb(TL.ntiles);
+      for (fem_uint t = 0; t < TL.ntiles; t++) {
+        const fem_uint *mt = &TL.meta[16 * (size_t)t];
+        const fem_uint cnt = mt[5 + mt[4]] - mt[5];
+        nb[t].push_back(t);
+        for (fem_uint i = 0; i < cnt; i++) {
+          const fem_uint o = owner[TL.ghost[mt[1] + i]];
+          if (nb[t].back() != o) { nb[t].push_back(o); nb[o].push_back(t); }
+        }
+      }
+      for (fem_uint t = 0; t < TL.ntiles; t++) {
+        std::vector<fem_uint> &tmp = nb[t];
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        dep.insert(dep.end(), tmp.begin(), tmp.end());
+        depOff[t + 1] = (fem_uint)dep.size();
+      }
+      ok(p->pctl.alloc(kPersistCtl + (size_t)TL.ntiles)) && ok(hipMemset(p->pctl.p, 0, sizeof(fem_uint) * (kPersistCtl + (size_t)TL.ntiles))) &&
+      ok(p->pdepOff.alloc(depOff.size())) && ok(p->pdepOff.upload(depOff.data())) &&
+      ok(p->pdep.alloc(dep.size())) && ok(p->pdep.upload(dep.data()));
+    }
     ok(p->tmeta.alloc(TL.meta.size())) && ok(p->tmeta.upload(TL.meta.data())) &&
     ok(p->tghost.alloc(TL.ghost.size())) && (TL.ghost.empty() || ok(p->tghost.upload(TL.ghost.data()))) &&
     ok(p->tidx2.alloc(TL.idx2.size())) && ok(p->tidx2.upload(TL.idx2.data())) &&
@@ -862,6 +956,11 @@ int fem_plan_get_state(fem_plan *p, double *nFn, double *cFn) {
   return fem::guarded("fem_plan_get_state", [&]() -> int {
   if (!p || !nFn || !cFn) return fail(FEM_ERR_INVALID, "fem_plan_get_state: null");
   HIP_TRY(hipDeviceSynchronize());
+  if (p->persist > 0 && p->pctl.p) {            // the experimental persistent kernel gives up instead of hanging
+    fem_uint gaveUp = 0;
+    HIP_TRY(hipMemcpy(&gaveUp, p->pctl.p + 128, sizeof gaveUp, hipMemcpyDeviceToHost));
+    if (gaveUp) return fail(FEM_ERR_DEVICE, ("tile_step_persist_kernel: gave up waiting for a neighbouring tile at item " + std::to_string(gaveUp - 1)).c_str());
+  }
   if (p->precision == FEM_PREC_F32) {
     std::vector<float> h(2 * (size_t)p->V);
     HIP_TRY(hipMemcpy(h.data(), p->state[p->cur], sizeof(float) * h.size(), hipMemcpyDeviceToHost));
@@ -913,6 +1012,13 @@ int fem_plan_flip(fem_plan *p) {
   return FEM_OK;
 }
 
+int fem_plan_persist_groups(const fem_plan *p, int *groups) {
+  if (!p || !groups) return fail(FEM_ERR_INVALID, "fem_plan_persist_groups: null");
+  *groups = (p->ksteps > 0 && p->persist > 0 && p->packed && p->precision == FEM_PREC_F32 && p->pctl.p &&
+             (p->tcfg == kDefaultTileCfg || p->tcfg == kDefaultTileCfgWide)) ? p->persist : 0;
+  return FEM_OK;
+}
+
 int fem_plan_tile_classes(const fem_plan *p, fem_uint *n_interior, fem_uint *n_boundary, fem_uint *n_ghost) {
   if (!p || p->ksteps <= 0) return fail(FEM_ERR_INVALID, "fem_plan_tile_classes: not a tiled plan");
   if (n_interior) *n_interior = p->nInterior;
@@ -923,6 +1029,33 @@ int fem_plan_tile_classes(const fem_plan *p, fem_uint *n_interior, fem_uint *n_b
 
 int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, void *stream) {
   if (!p || nsteps < 0) return fail(FEM_ERR_INVALID, "fem_plan_run: bad argument");
+  if (p->ksteps > 0 && p->persist > 0 && p->packed && p->precision == FEM_PREC_F32 &&
+      (p->tcfg == kDefaultTileCfg || p->tcfg == kDefaultTileCfgWide)) {      // several groups per launch (persistRule)
+    fem_model dm;
+    if (!model) { fem_default_model(&dm); model = &dm; }
+    const ModelT<float> mf = {(float)(model->nMax - p->base_n), (float)model->D, (float)model->r, (float)model->alpha,
+                              (float)model->S, (float)dt, (float)p->base_n, (float)(1.0 / (1.0 + p->base_n))};
+    for (int done = 0; done < nsteps;) {
+      const int left = nsteps - done;
+      const fem_uint groups = (fem_uint)std::min(p->persist, (left + p->ksteps - 1) / p->ksteps);
+      if (groups < 2) {                        // a single group: nothing to hand over, the plain launch is cheaper
+        const int rc = launchTiles(p, 0, p->ntiles, left, dt, model, stream);
+        if (rc != FEM_OK) return rc;
+        p->cur ^= 1;
+        break;
+      }
+      const int steps = std::min(left, (int)groups * p->ksteps);
+      const int lastSteps = steps - ((int)groups - 1) * p->ksteps;
+      const hipError_t e = p->tcfg == kDefaultTileCfg
+          ? launchTilePersist<kDefaultTileCfg>(p, p->state[p->cur], p->state[p->cur ^ 1], p->ksteps, lastSteps, groups, mf, (hipStream_t)stream)
+          : launchTilePersist<kDefaultTileCfgWide>(p, p->state[p->cur], p->state[p->cur ^ 1], p->ksteps, lastSteps, groups, mf, (hipStream_t)stream);
+      if (e != hipSuccess) return fail(FEM_ERR_DEVICE, "tile_step_persist_kernel launch", e);
+      p->cur ^= (int)(groups & 1u);
+      done += steps;
+    }
+    HIP_TRY(hipGetLastError());
+    return FEM_OK;
+  }
   if (p->ksteps > 0) {                       // fused tiles: up to ksteps time steps per launch
     for (int done = 0; done < nsteps;) {
       const int c = std::min(p->ksteps, nsteps - done);

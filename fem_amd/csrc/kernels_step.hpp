@@ -228,18 +228,38 @@ constexpr bool kTileRowFence = FEM_TILE_ROW_FENCE != 0;
 // largest coefficient, 8 x an fp32 rounding), decoded once per launch into the same register rows.  A tile's block
 // keeps its place and size in the coefficient array (16 bytes per entry from row_off on): the W * rows_pad records
 // fill its first three quarters, the rows_pad scales follow; the extras of wide rows stay four floats behind the block.
-template <typename T, int TPB, int R, int W, int MINW, int X, int PRO, int PK = 0>
-__global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
+// State accesses of the tile body.  COH (the persistent kernel, where another workgroup of the SAME launch wrote the rows):
+// agent-scope relaxed atomics = write-through stores / loads that bypass the L1 (global_store/load ... sc1), 8 bytes each.
+template <bool COH, typename T2> __device__ __forceinline__ T2 state_load(const T2 *p) {
+  if constexpr (COH && sizeof(T2) == 8) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    T2 o;
+    __builtin_memcpy(&o, &v, 8);
+    return o;
+  } else {
+    return *p;
+  }
+}
+template <bool COH, typename T2> __device__ __forceinline__ void state_store(T2 *p, T2 v) {
+  if constexpr (COH && sizeof(T2) == 8) {
+    unsigned long long u;
+    __builtin_memcpy(&u, &v, 8);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    *p = v;
+  }
+}
+
+template <typename T, int TPB, int R, int W, int X, int PRO, int PK, int COH>
+__device__ __forceinline__ void tile_body(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
-    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
-    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile,
+    uint maxLocal, uint maxExtra, int nsteps, const ModelT<T> &m) {
   static_assert(!PK || sizeof(T) == 4, "packed operator records: fp32 plans");
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   extern __shared__ __align__(16) unsigned char tile_smem[];
-  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
-  const uint tile = tile0 + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);   // tiles [tile0, tile0 + ntiles)
   const uint *mt = meta + 16 * (size_t)tile;
   const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], k = mt[4];
   const uint n0 = mt[5], mk = mt[5 + k];
@@ -369,7 +389,7 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
 #pragma unroll
     for (int u = 0; u < SU; u++) {
       const uint i = i0 + t + TPB * u;
-      sv[u] = src[i < n0 ? base + i : gi[u]];
+      sv[u] = state_load<(COH == 1 || COH == 2)>(&src[i < n0 ? base + i : gi[u]]);
     }
     if (IXL && i0 == 0) {
 #pragma unroll
@@ -450,7 +470,103 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
     __syncthreads();
     T2 *tmp = cur; cur = nxt; nxt = tmp;
   }
-  for (uint i = t; i < n0; i += TPB) dst[base + i] = cur[i];
+  for (uint i = t; i < n0; i += TPB) state_store<(COH == 1 || COH == 3)>(&dst[base + i], cur[i]);
+}
+
+template <typename T, int TPB, int R, int W, int MINW, int X, int PRO, int PK = 0>
+__global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
+    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
+    uint maxLocal, uint maxExtra, int nsteps, ModelT<T> m) {
+  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
+  const uint tile = tile0 + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);   // tiles [tile0, tile0 + ntiles)
+  tile_body<T, TPB, R, W, X, PRO, PK, 0>(src, dst, meta, ghost, idx2, coef, xinfo, tile, maxLocal, maxExtra, nsteps, m);
+}
+
+// ---------------------------------------------------------------------------
+// The same tiles without a launch-wide barrier between groups of k steps (chosen by tile count,
+// device.hip:persistRule).  A fixed grid of workgroups draws (group, tile) items from tickets, in group-major tile order.
+// Item (g, T) reads buffer g % 2 and writes the other; it may start when every tile within T's rings (dep[], symmetric,
+// T itself included) has PUBLISHED group g - 1: flag[tile] = number of groups that tile has finished.  The same condition
+// covers the write-after-read hazard on the ping-pong buffers: a neighbour one group ahead would need T's flag first.
+// Progress: a workgroup holds an item only while it runs or waits, and an item waits only for items of the group before,
+// which have smaller tickets in their ranges; workgroups start in launch order, so each of the eight ranges has a live
+// workgroup from the moment eight are resident until the range is exhausted (tests/test_persist_protocol.py models it).
+// Hand-off form (MI355X guide, Guideline 16, R1): every state store write-through (sc1), every storing wave drains
+// (s_waitcnt vmcnt(0)), the workgroup's barrier, then the flag store (sc1); consumer: one wave polls the flags (sc1
+// loads, bounded: a give-up sets ctl[128] and every workgroup leaves), barrier, then every state load sc1.
+// CM (rate probes, FEM_TILE_PERSIST_COH): 1 as described; 0 plain loads and stores, 2 sc1 loads only, 3 sc1 stores only
+// -- all four run at the same rate (200 G DOF-it/s with one ticket for all tiles, 304..336 G with the eight ranges,
+// 16.4M rows): what the kernel is sensitive to is which XCD's L2 a tile's neighbours went through, not the sc1 bits.
+// ---------------------------------------------------------------------------
+template <typename T, int TPB, int R, int W, int MINW, int X, int PRO, int PK, int CM = 1>
+__global__ __launch_bounds__(TPB, MINW) void tile_step_persist_kernel(
+    typename Vec<T>::t2 *__restrict__ buf0, typename Vec<T>::t2 *__restrict__ buf1,
+    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile0, uint ntiles,
+    uint maxLocal, uint maxExtra, int ksteps, int lastSteps, uint ngroups, ModelT<T> m, uint *__restrict__ ctl,
+    uint *__restrict__ flags, const uint *__restrict__ depOff, const uint *__restrict__ dep, int useDeps, uint ldsItem) {
+  extern __shared__ __align__(16) unsigned char tile_smem[];
+  uint *itemSlot = reinterpret_cast<uint *>(tile_smem + ldsItem);      // [0] item, [1] give-up word at the draw, [2] after the poll
+  const uint t = threadIdx.x;
+  // Tiles in eight contiguous ranges, one per XCD, each with a ticket of its own (ctl[16 * x]; the give-up word is
+  // ctl[128]): workgroup b runs on XCD b % 8 under dispatch-order placement, so neighbouring tiles share an L2 as in the
+  // launch-per-group kernel's blockIdx -> tile map.  Placement is a matter of speed only: every hand-off is agent scope.
+  const uint xcd = blockIdx.x & 7u, q8 = ntiles >> 3, r8 = ntiles & 7u;
+  const uint xlo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, xn = q8 + (xcd < r8 ? 1u : 0u);
+  const uint total = ngroups * xn;
+  uint *__restrict__ ticket = ctl + 16 * xcd;
+  uint *__restrict__ giveup = ctl + 128;
+  // Everything one thread would do for its workgroup (draw a ticket, poll, publish) is done by WAVE 0 WITH ALL ITS LANES
+  // behind a wave-uniform branch.  An `if (threadIdx.x == 0)` in this loop is lane-divergent control flow whose result
+  // feeds the loop's exit: the structuriser then runs the ticket draw in an outer loop that lane 0 only reaches once
+  // every other lane has left the inner one -- which they never do, since they wait for the ticket (the first version
+  // of this kernel span on its first item for ever; most likely round 2's unresolved "multi-tile bug" too).
+  const bool wave0 = __builtin_amdgcn_readfirstlane(t >> 6) == 0;
+  for (;;) {
+    if (wave0) {
+      // 64 lanes add 1 each (the compiler folds them into one add of 64 and hands out consecutive values): the item is
+      // the first lane's value / 64; every lane writes the same two words.  (Drawing the NEXT item's ticket here, to
+      // hide the round trip behind the running item: no gain at 1M and 16M rows, -19 % at 256k, where a workgroup
+      // then sits on an item that an idle one could run.)
+      const uint v = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      itemSlot[0] = __builtin_amdgcn_readfirstlane(v) >> 6;
+      itemSlot[1] = __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const uint item = __builtin_amdgcn_readfirstlane(itemSlot[0]), aborted = __builtin_amdgcn_readfirstlane(itemSlot[1]);
+    if (item >= total || aborted) break;
+    const uint g = item / xn, tile = tile0 + xlo + (item - g * xn);
+    uint stop = 0;
+    if (useDeps && g > 0) {
+      if (wave0) {
+        const uint lane = t & 63u;
+        const uint d0 = depOff[tile], nd = depOff[tile + 1] - d0;
+        for (uint d = lane; d < nd; d += 64) {
+          const uint other = dep[d0 + d];
+          uint spins = 0;
+          while (__hip_atomic_load(&flags[other], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g) {
+            __builtin_amdgcn_s_sleep(4);
+            // bounded: a give-up (or anybody else's) ends the whole grid within microseconds
+            if (++spins > (1u << 16)) { __hip_atomic_store(giveup, 1u + item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 63u) == 0 && __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: keeps the state loads below the poll
+        itemSlot[2] = __hip_atomic_load(giveup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (a word of its own: slow waves may still be reading [1])
+      }
+      __syncthreads();
+      stop = __builtin_amdgcn_readfirstlane(itemSlot[2]);
+    }
+    if (stop) break;                                               // somebody gave up: leave without touching the state
+    typename Vec<T>::t2 *src = (g & 1u) ? buf1 : buf0, *dst = (g & 1u) ? buf0 : buf1;
+    tile_body<T, TPB, R, W, X, PRO, PK, CM>(src, dst, meta, ghost, idx2, coef, xinfo, tile, maxLocal, maxExtra,
+                                            g + 1 == ngroups ? lastSteps : ksteps, m);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its write-through stores
+    __syncthreads();
+    if (wave0) __hip_atomic_store(&flags[tile], g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // all lanes, one word
+  }
 }
 
 

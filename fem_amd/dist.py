@@ -51,6 +51,11 @@ class SingleRun:
         self.steps_per_launch = max(1, ksteps)
         sb = 4 if precision == "f32" else 8
         self.layout_bytes_per_launch = self.plan.operator_bytes() + 4 * sb * om.V   # operator + state r/w
+        groups = self.plan.persist_groups() if ksteps > 0 else 0
+        if groups > 0:          # mid-sized plans: several groups of k steps per launch, tiles handed over inside it
+            self.kernel_name = "tile_step_persist_kernel"
+            self.steps_per_launch = groups * ksteps
+            self.layout_bytes_per_launch *= groups              # every group streams the operator and the state again
 
     def run(self, nsteps, stream=None):
         self.plan.run(nsteps, self.dt, self.model, stream.cuda_stream if stream is not None else None)
