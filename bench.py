@@ -395,8 +395,8 @@ def main():
     # (the library gives regular meshes the 2048-row register tile; meshes with rows wider than 6 entries and
     # plans below 1.5M rows -- kLargeMeshRows in device.hip, per rank -- get the 1536-row one)
     small = scanned or V_total // world < 1500000
-    if small and not scanned and world == 1 and args.precision == "f32" and 192 <= V_total // 975 <= 4096:
-        # ... except whole meshes of 192..4096 such tiles: fem_plan_run runs those in persistent launches (device.hip:
+    if small and not scanned and world == 1 and args.precision == "f32" and 192 <= V_total // 975 <= 2400:
+        # ... except whole meshes of 192..2400 such tiles: fem_plan_run runs those in persistent launches (device.hip:
         # persistRule), which do not need many small tiles to fill the workgroup slots
         small = False
     if args.fuse < 0:
@@ -533,7 +533,9 @@ def main():
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
         spl = getattr(runner, "steps_per_launch", 1)
-        launches = -(-args.steps // spl)
+        launches = runner.launch_count(args.steps) if hasattr(runner, "launch_count") else -(-args.steps // spl)
+        if hasattr(runner, "kernel_for"):                   # short runs of a mid-sized plan go one launch per group
+            runner.kernel_name = runner.kernel_for(args.steps)
         kernel_ms = dev_ms / launches                       # average launch duration, device events
         v_per_launch = runner.vertices_per_launch           # owned vertices this rank advances per launch
         achieved = ALG_BYTES_PER_VERTEX_STEP * v_per_launch * (args.steps / launches) / (kernel_ms * 1e-3) / 1e9

@@ -501,12 +501,26 @@ class Plan:
         """which = 0: from the current state buffer, 1: from the next one (see launch_tiles)"""
         _check(lib.fem_plan_pack_halo_from(self.h, which, dst_ptr, vp(stream or 0)))
 
-    def persist_groups(self):
+    def persist_groups(self, with_min=False):
         """groups of ksteps steps one launch of run() may cover: 0 = one launch per group (tile_step_kernel), n > 0 = up
-        to n groups per launch of tile_step_persist_kernel (fem_plan_persist_groups)"""
-        g = C.c_int()
-        _check(lib.fem_plan_persist_groups(self.h, C.byref(g)))
-        return g.value
+        to n groups per launch of tile_step_persist_kernel (fem_plan_persist_groups); with_min: (n, the fewest groups
+        a persistent launch is used for -- a run's remainder below that goes one launch per group)"""
+        g, gmin = C.c_int(), C.c_int()
+        _check(lib.fem_plan_persist_groups(self.h, C.byref(g), C.byref(gmin)))
+        return (g.value, gmin.value) if with_min else g.value
+
+    def launch_count(self, nsteps):
+        """(launches, persistent launches among them) run(nsteps) makes on a fused plan"""
+        k = self.tile_info()["ksteps"]
+        g, gmin = self.persist_groups(with_min=True)
+        total, persistent, left = 0, 0, int(nsteps)
+        while left > 0:
+            groups = min(g, -(-left // k))
+            if groups < max(gmin, 1):
+                total += -(-left // k)
+                break
+            total, persistent, left = total + 1, persistent + 1, left - min(left, groups * k)
+        return total, persistent
 
     def tile_classes(self):
         """(interior, boundary, ghost) tile counts; the tiles are ordered in that sequence"""

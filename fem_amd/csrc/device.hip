@@ -106,7 +106,7 @@ struct fem_plan {
   int ksteps = 0, tcfg = 0;
   // tile_step_persist_kernel: up to `persist` groups of k steps per launch (0: one launch per group; FEM_TILE_PERSIST,
   // else by tile count: persistRule); its control words, the per-tile "groups finished" flags, the tiles each tile waits for
-  int persist = -1, persist_deps = 1, persist_grid = 0;
+  int persist = -1, persist_min = 2, persist_deps = 1, persist_grid = 0;
   DevBuf<fem_uint> pctl, pdepOff, pdep;
   int device = -1;                  // ordinal of the GPU that was current when the plan was created (owns every buffer)
   int prologue = -1, sell_nt = -1;   // FEM_TILE_PROLOGUE / FEM_SELL_NT as read when the plan was created (-1: by operator size)
@@ -263,14 +263,17 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
 
 // `groups` groups of up to ksteps steps in ONE launch of a fixed grid of workgroups that draw (group, tile) items from a
 // ticket and hand tiles over through per-tile flags (kernels_step.hpp): no chip-wide drain between groups.  Packed fp32
-// plans on the two default register tiles.  Same-session A/B against one launch per group (sphere, 975-row tiles, k = 7,
-// bit-identical states): 263 tiles +7 %, 1 056 tiles +17..22 % (290 -> 340 G DOF-it/s at 10 groups, 350 at 50),
-// 4 215 tiles +-0, 16 848 tiles -7 % (the per-item ticket / poll / publish chain costs more than the drain of a launch
-// that lasts 33 tile lifetimes), 2 tiles -25 %.  Hence the rule: plans of 192..4096 tiles, 32 groups per launch.
-constexpr int kPersistGroups = 32;
-constexpr fem_uint kPersistMinTiles = 192, kPersistMaxTiles = 4096;
+// plans on the two default register tiles.  A/B against one launch per group in alternating rounds of 7000 steps in one
+// process (sphere, 975-row tiles, k = 7, 32 groups per launch, bit-identical states; profiles/r03_persist_rounds.txt):
+// 263 tiles 176 : 176 G DOF-it/s, 1 056 tiles 388 : 370 (+4.8 %; in a cold 1000-step run as bench.py times it 310 : 286,
+// the long launches get up to speed sooner), 2 387 tiles 324 : 323, 4 215 tiles 327 : 349 (-6 %), 16 848 tiles 327 : 350
+// (the per-item ticket / poll / publish chain costs more than the drain of a launch that lasts 33 tile lifetimes).
+// Short launches lose: 8 groups 363 : 370, 4 groups 309 : 322, 2 groups 281 : 315 at 1 056 tiles (the memset, the launch
+// and its tail are paid per launch).  Hence the rule: plans of 192..2400 tiles, launches of 12..32 groups; anything
+// else goes one launch per group.  FEM_TILE_PERSIST=n forces launches of 2..n groups at any size, =0 turns it off.
+constexpr int kPersistGroups = 32, kPersistMinGroups = 12;
+constexpr fem_uint kPersistMinTiles = 192, kPersistMaxTiles = 2400;
 static int persistRule(fem_uint ntiles) { return ntiles >= kPersistMinTiles && ntiles <= kPersistMaxTiles ? kPersistGroups : 0; }
-
 constexpr size_t kPersistCtl = 144;      // eight tickets on lines of their own, the give-up word at [128]; the flags follow
 template <int C>
 static hipError_t launchTilePersist(fem_plan *p, void *buf0, void *buf1, int ksteps, int lastSteps, fem_uint groups,
@@ -699,7 +702,7 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     p->maxLocal = (TL.maxLocal + 1) & ~1u; p->maxExtra = TL.maxExtra; p->tile_entries = TL.coef.size() / 4;
     p->tile_bytes = (uint64_t)(TL.coef.size() / 4) * (4 * sb + 2) + (uint64_t)TL.ghost.size() * 4 + (uint64_t)TL.meta.size() * 4 +
                     (uint64_t)TL.xinfo.size() * 4;
-    if (p->persist < 0) p->persist = persistRule(TL.ntiles);
+    if (p->persist < 0) { p->persist = persistRule(TL.ntiles); p->persist_min = kPersistMinGroups; }
     if (p->persist > 0) {
       // tiles each tile waits for: the owners of its ring rows, and itself (another workgroup may run its next group)
       std::vector<fem_uint> owner(op.V, 0u), depOff(TL.ntiles + 1, 0u), dep;
@@ -1012,10 +1015,11 @@ int fem_plan_flip(fem_plan *p) {
   return FEM_OK;
 }
 
-int fem_plan_persist_groups(const fem_plan *p, int *groups) {
+int fem_plan_persist_groups(const fem_plan *p, int *groups, int *min_groups) {
   if (!p || !groups) return fail(FEM_ERR_INVALID, "fem_plan_persist_groups: null");
   *groups = (p->ksteps > 0 && p->persist > 0 && p->packed && p->precision == FEM_PREC_F32 && p->pctl.p &&
              (p->tcfg == kDefaultTileCfg || p->tcfg == kDefaultTileCfgWide)) ? p->persist : 0;
+  if (min_groups) *min_groups = *groups > 0 ? p->persist_min : 0;
   return FEM_OK;
 }
 
@@ -1038,10 +1042,14 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
     for (int done = 0; done < nsteps;) {
       const int left = nsteps - done;
       const fem_uint groups = (fem_uint)std::min(p->persist, (left + p->ksteps - 1) / p->ksteps);
-      if (groups < 2) {                        // a single group: nothing to hand over, the plain launch is cheaper
-        const int rc = launchTiles(p, 0, p->ntiles, left, dt, model, stream);
-        if (rc != FEM_OK) return rc;
-        p->cur ^= 1;
+      if ((int)groups < p->persist_min) {       // too few groups to pay for a persistent launch: one launch per group
+        for (int d2 = 0; d2 < left;) {
+          const int c = std::min(p->ksteps, left - d2);
+          const int rc = launchTiles(p, 0, p->ntiles, c, dt, model, stream);
+          if (rc != FEM_OK) return rc;
+          p->cur ^= 1;
+          d2 += c;
+        }
         break;
       }
       const int steps = std::min(left, (int)groups * p->ksteps);

@@ -57,6 +57,19 @@ class SingleRun:
             self.steps_per_launch = groups * ksteps
             self.layout_bytes_per_launch *= groups              # every group streams the operator and the state again
 
+    def launch_count(self, nsteps):
+        """launches run(nsteps) makes (bench.py's average launch duration): a run too short for persistent launches,
+        or its remainder, goes one launch per group"""
+        if self.ksteps <= 0:
+            return int(nsteps)
+        return self.plan.launch_count(nsteps)[0]
+
+    def kernel_for(self, nsteps):
+        """the kernel run(nsteps) spends its time in"""
+        if self.ksteps <= 0:
+            return self.kernel_name
+        return "tile_step_persist_kernel" if self.plan.launch_count(nsteps)[1] > 0 else "tile_step_kernel"
+
     def run(self, nsteps, stream=None):
         self.plan.run(nsteps, self.dt, self.model, stream.cuda_stream if stream is not None else None)
 

@@ -438,12 +438,13 @@ int fem_plan_pack_halo(fem_plan *p, uint64_t dst_dev, void *stream);
  *   fem_plan_state_buffer / fem_plan_pack_halo_from: which = 0 current, 1 next. */
 int fem_plan_tile_classes(const fem_plan *p, fem_uint *n_interior, fem_uint *n_boundary, fem_uint *n_ghost);
 /* How fem_plan_run launches a fused plan (no counterpart in the reference, whose loop is one launch per step,
- * src/main.cpp:558-562): *groups = 0, one launch per group of ksteps steps; n > 0, up to n groups per launch of the
+ * src/main.cpp:558-562): *groups = 0, one launch per group of ksteps steps; n > 0, *min_groups .. n groups per launch of the
  * persistent tile kernel (tiles handed from group to group through per-tile flags inside the launch; packed fp32 plans
- * of 192..4096 tiles by default, FEM_TILE_PERSIST=0 turns it off, =n forces n).  Results are bit-identical either way.
+ * of 192..2400 tiles by default, and only for launches of at least 12 groups; FEM_TILE_PERSIST=0 turns it off, =n forces
+ * launches of 2..n groups at any size).  Results are bit-identical either way.
  * Should a tile wait beyond its bound for a neighbour (never observed), the launch ends early and the next
  * fem_plan_get_state returns FEM_ERR_DEVICE instead of a state. */
-int fem_plan_persist_groups(const fem_plan *p, int *groups);
+int fem_plan_persist_groups(const fem_plan *p, int *groups, int *min_groups);
 int fem_plan_launch_tiles(fem_plan *p, fem_uint first, fem_uint count, int nsteps, double dt,
                           const fem_model *model, void *stream);
 int fem_plan_flip(fem_plan *p);
