@@ -1,0 +1,13 @@
+#!/bin/bash
+# usage (build machine, after tools/r03_profiles.sh has run on the GPU box): bash tools/r03_summarize.sh
+# condenses gpurun_out/r03_* into profiles/ and records each traffic figure under its run's own traffic key
+for tag in r03_sphere16m_fused7_rec12 r03_scan8m_fused5_rec12 r03_deform4m r03_sphere16m_sell_rec12 r03_sphere1m_persist; do
+  d=gpurun_out/$tag
+  [ -s $d/bench_under_rocprof.json ] || { echo "missing $d"; continue; }
+  key=$(python3 -c "import json,sys; print(json.load(open('$d/bench_under_rocprof.json'))['roofline']['traffic_key'])")
+  cp $d/bench_under_rocprof.json profiles/${tag}_bench_under_rocprof.json
+  python3 tools/summarize_prof.py $tag $d/stats $d/fetch $d/write "$key" > /dev/null || echo "summary of $tag failed"
+  echo "$tag -> $key"
+done
+cp gpurun_out/r03_sphere16m_fused7_rec12_sq_counters.txt profiles/ 2>/dev/null
+python3 -c "import json; print(json.dumps(json.load(open('profiles/traffic.json')), indent=1)[:3000])"
