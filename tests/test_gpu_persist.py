@@ -63,6 +63,25 @@ def test_persistent_launches_equal_launch_per_group_and_oracle(cfg, ksteps, n0ro
         assert np.array_equal(again[0], out[0][0]) and np.array_equal(again[1], out[0][1])
 
 
+@pytest.mark.parametrize("nu,nparts", [(8, 1), (16, 2), (20, 5), (24, 7)])
+def test_persistent_launches_with_fewer_tiles_than_ranges(nu, nparts, monkeypatch):
+    """1, 2, 5 and 7 tiles: some of the kernel's eight tile ranges are empty (their workgroups leave at once) and the
+    grid is the minimum of eight workgroups; one tile depends on nothing but itself"""
+    case = Case(*fa.make_icosphere(nu, 0.1), nparts)
+    case.mesh.init_stats(fa.PREC_F64)
+    plain, pers = _plans(case, 4, monkeypatch, 5, 8)
+    assert pers.tile_info()["ntiles"] == nparts
+    n0, c0 = case.n0.astype(np.float32).astype(np.float64), case.c0.astype(np.float32).astype(np.float64)
+    out = []
+    for plan in (plain, pers):
+        plan.set_state(n0, c0)
+        plan.run(43, case.dt, case.model)
+        out.append(plan.get_state())
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    n_ref, c_ref = case.ostats(ol.F64).step(n0, c0, case.dt, 43, case.model.as_array())
+    parity(out[1][0], out[1][1], n_ref, c_ref, TOL_F32)
+
+
 def test_persistent_rule_by_tile_count_and_a_mid_sized_run(monkeypatch):
     """the library's own choice (fem_plan_persist_groups): plans of 192..2400 tiles run 12..32 groups per launch,
     smaller and larger ones and every plan that is not fp32 with packed records one launch per group; and the size the
