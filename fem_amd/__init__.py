@@ -248,6 +248,16 @@ class Mesh:
         _check(lib.fem_compute_vertex_gradients_cpu(self.h, _ptr(fg, f64p), _ptr(out, f64p)))
         return out
 
+    def wide_rows_first(self, width=6):
+        """-> (Mesh, new_index): vertices renumbered stably by their number of entries beyond `width`, most first
+        (fem_mesh_wide_rows_first); (self, None) when no row is wider"""
+        new_index = np.empty(self.V, np.int64)
+        oh = vp()
+        wide = _check(lib.fem_mesh_wide_rows_first(self.h, C.c_int(width), _ptr(new_index, i64p), C.byref(oh)))
+        if wide == 0 or not oh:
+            return self, None
+        return Mesh(handle=oh), new_index
+
     def partition_vertices(self, n, method="rcb"):
         """vertex -> part id; method "rcb" (coordinate bisection), "graph" (graph bisection), "auto" (rcb unless its cut says
         the coordinates mislead, then graph) or "multilevel" (multilevel k-way on the dual graph, the METIS_PartMeshDual stage)"""

@@ -203,6 +203,47 @@ int fem_partition_vertices_multilevel(const fem_mesh *m, int n, int64_t *npart, 
   });
 }
 
+int fem_mesh_wide_rows_first(const fem_mesh *m, int width, int64_t *new_index, fem_mesh **out) {
+  return fem::guarded("fem_mesh_wide_rows_first", [&]() -> int {
+  if (!m || !out || width < 1) return fail(FEM_ERR_INVALID, "fem_mesh_wide_rows_first: bad argument");
+  *out = nullptr;
+  const fem::SimpleTriMesh &om = m->mesh;
+  const int64_t V = om.n_vertices(), F = om.n_faces();
+  if (om.H == 0 && F > 0) return fail(FEM_ERR_INVALID, "fem_mesh_wide_rows_first: mesh without topology");
+  // stable counting sort by the number of entries beyond `width`, most first
+  auto extra = [&](int64_t v) { const int d = om.rowptr[v + 1] - om.rowptr[v]; return d > width ? d - width : 0; };
+  int maxExtra = 0;
+  int64_t wide = 0;
+  for (int64_t v = 0; v < V; v++) { const int x = extra(v); maxExtra = std::max(maxExtra, x); wide += x > 0; }
+  if (wide == 0) {
+    if (new_index) for (int64_t v = 0; v < V; v++) new_index[v] = v;
+    return 0;
+  }
+  std::vector<int64_t> start((size_t)maxExtra + 2, 0);
+  for (int64_t v = 0; v < V; v++) start[(size_t)(maxExtra - extra(v)) + 1]++;
+  for (int k = 0; k <= maxExtra; k++) start[(size_t)k + 1] += start[(size_t)k];
+  std::vector<int64_t> pos((size_t)V);
+  for (int64_t v = 0; v < V; v++) pos[(size_t)v] = start[(size_t)(maxExtra - extra(v))]++;
+  fem_mesh *o = new (std::nothrow) fem_mesh();
+  if (!o) return fail(FEM_ERR_ALLOC, "out of memory");
+  o->mesh.points.resize(3 * (size_t)V);
+  o->mesh.faces.resize(3 * (size_t)F);
+  const bool col = om.colors.size() == om.points.size();
+  if (col) o->mesh.colors.resize(3 * (size_t)V);
+  for (int64_t v = 0; v < V; v++)
+    for (int k = 0; k < 3; k++) {
+      o->mesh.points[3 * (size_t)pos[(size_t)v] + k] = om.points[3 * (size_t)v + k];
+      if (col) o->mesh.colors[3 * (size_t)pos[(size_t)v] + k] = om.colors[3 * (size_t)v + k];
+    }
+  for (size_t i = 0; i < 3 * (size_t)F; i++) o->mesh.faces[i] = (fem_uint)pos[om.faces[i]];
+  const int rc = o->mesh.update_topology();
+  if (rc != FEM_OK) { delete o; return fail(rc, "fem_mesh_wide_rows_first: renumbered mesh invalid"); }
+  if (new_index) std::copy(pos.begin(), pos.end(), new_index);
+  *out = o;
+  return (int)std::min<int64_t>(wide, 0x7fffffff);
+  });
+}
+
 int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, int64_t *perm_v,
                         int64_t *perm_f, fem_uint *node_parts, fem_uint *element_parts,
                         fem_mesh **ordered) {

@@ -501,6 +501,15 @@ int main(int argc, char **argv) {
 
   fem_mesh *original = loadMesh(o);
   if (!original) return 1;
+  if (o.native) {
+    // irregular meshes on the native plans: rows of more than 6 entries numbered first, so that they lead every part
+    // and share waves in the fused kernel (the Python drivers do the same: fem_amd/dist.py:_partition)
+    fem_mesh *renumbered = nullptr;
+    const int wide = fem_mesh_wide_rows_first(original, 6, nullptr, &renumbered);
+    if (!ok(wide, "wide rows first")) { fem_mesh_destroy(original); return 1; }
+    if (renumbered) { fem_mesh_destroy(original); original = renumbered; }
+    if (o.verbose) std::printf("%d rows of more than 6 entries%s\n", wide, wide ? ": numbered first" : "");
+  }
   int V = 0;
   fem_mesh_counts(original, &V, nullptr, nullptr);
   if (o.native && !partsGiven) o.startN = o.endN = std::max(1, V / o.rowsPerPart);

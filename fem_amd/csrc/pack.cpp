@@ -280,7 +280,7 @@ int packSellLayout(const RowOp &op, SellLayout &o) {
 // Native layout 2: tiles for the fused k-step kernel.  A tile = a contiguous range of rows (a
 // partition, or a piece of one when the partition does not fit) that the kernel advances k steps
 // in one launch, plus the k rings of rows around it: local list = owned rows, then ring 1, ...,
-// ring k (each ring ascending).  m[j] = number of local rows within j edges of the owned range.
+// ring k (each ring: rows wider than W first, widest first, then ascending).  m[j] = number of local rows within j edges of the owned range.
 // The kernel keeps the state of all m[k] local rows in LDS and the operator rows of the first
 // m[k-1] in registers (thread t holds rows t, t+T, ..., at most R of them), so a tile must
 // satisfy m[k-1] <= T*R and m[k] <= maxLocal; ranges that do not are split in halves.
@@ -327,7 +327,13 @@ int packTileLayout(const RowOp &op, const std::vector<std::pair<uint, uint>> &ra
           if (stamp[u] != tileNo) { stamp[u] = tileNo; local.push_back(u); }
         }
       }
-      std::sort(local.begin() + frontE, local.end());
+      // each ring ascending -- behind its rows of more than W entries, widest first (irregular meshes): their extras
+      // run in a loop that a wave executes if ANY of its 64 rows has one, so wide rows are kept together (drivers
+      // number the owned rows the same way: fem_mesh_wide_rows_first)
+      std::sort(local.begin() + frontE, local.end(), [&](uint a, uint c) {
+        const uint wa = std::max(op.rowptr[a + 1] - op.rowptr[a], W), wc = std::max(op.rowptr[c + 1] - op.rowptr[c], W);
+        return wa != wc ? wa > wc : a < c;
+      });
       frontB = frontE;
       m[ring] = (uint)local.size();
       if (ring == ksteps - 1 && m[ring] > T * R) fits = false;   // rows held in registers

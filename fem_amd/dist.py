@@ -15,7 +15,15 @@ def _partition(mesh, nparts):
     """R0 stage by FEM_PARTITIONER: auto (default: rcb -- exactly equal parts, lowest cut and ring redundancy on the
     surfaces measured -- unless its cut says the coordinates mislead, then graph), rcb, graph, multilevel
     (METIS_PartMeshDual-style: multilevel k-way on the dual graph)"""
-    return mesh.partition(nparts, method=os.environ.get("FEM_PARTITIONER", "auto"))
+    pre = None
+    if os.environ.get("FEM_WIDE_FIRST", "1") != "0":
+        # irregular meshes: rows of more than 6 entries numbered first, so that they lead every part (the R2 stage keeps
+        # the input order inside a part) and share waves in the fused kernel (fem_mesh_wide_rows_first)
+        mesh, pre = mesh.wide_rows_first(6)
+    part = mesh.partition(nparts, method=os.environ.get("FEM_PARTITIONER", "auto"))
+    if pre is not None:
+        part.perm_v = part.perm_v[pre]          # new position of each vertex of the mesh the caller passed
+    return part
 
 
 def _time_step(om, model, rule):

@@ -186,6 +186,16 @@ int fem_partition_apply(const fem_mesh *original, int n, const int64_t *npart, i
                         int64_t *perm_f, fem_uint *node_parts, fem_uint *element_parts,
                         fem_mesh **ordered);
 
+/* Numbering pre-pass for irregular meshes, to run BEFORE the partition stage.  createOrderArray keeps the input order
+ * inside every part (partitioning_common.cpp:112-139: a stable counting sort), so the input numbering decides which
+ * rows sit side by side in a part -- and the fused kernel's loop over the entries beyond `width` (6 in the register
+ * tile) is run by a whole 64-row wave if any one of its rows has such an entry.  This renumbers the vertices stably by
+ * the number of those entries, most first (faces keep their order and corner order): wide rows then lead every part
+ * and fill a few waves instead of touching all of them (scanned-like 8.1M mesh: 228 -> 238 G DOF-it/s).  Returns the
+ * number of wide rows (>= 0; 0: *out = NULL, keep the input) or a negative fem_status; new_index[V] (optional) = new
+ * position of each old vertex.  No counterpart in the reference: its meshes are numbered by whoever wrote the file. */
+int fem_mesh_wide_rows_first(const fem_mesh *m, int width, int64_t *new_index, fem_mesh **out);
+
 /* Replaces initMeshStats(mesh, MeshStats&), mesh_function.cpp:27-67 (hot
  * fields of MeshStats, common.h:19-38).  precision = FEM_PREC_MIXED or
  * FEM_PREC_F64.  Arrays stay owned by the mesh handle. */

@@ -671,3 +671,40 @@ def test_scan_pathologies_all_paths(tmp_path):
         plan.run(23, dt, case.model)
         n_gpu, c_gpu = plan.get_state()
         parity(n_gpu, c_gpu, n_ref, c_ref, TOL_F32, tol_dev=DEV_SMOOTH_LARGE, what="f32 k=%d" % ksteps)
+
+
+@pytest.mark.gpu
+def test_wide_rows_first_numbering_on_the_fused_plan(monkeypatch):
+    """the drivers' numbering pre-pass for irregular meshes (fem_mesh_wide_rows_first: rows of more than 6 entries lead
+    every part, ring rows ordered the same way inside the tiles) changes which rows share a wave, not what is computed:
+    the fused fp32 and fp64 plans built through it agree with the f64 oracle on the re-ordered mesh, and -- mapped back
+    to the caller's numbering through perm_v -- with the run that keeps the input numbering (same smooth initial
+    condition, defined on the caller's vertices).  Observed on the deviation: f32 2e-7 against the oracle, 1e-7 between
+    the two numberings (the entries of a row are summed in another order); f64 1e-13."""
+    from fem_amd import dist as fdist
+    pts, tri = fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01)
+    n_in, c_in = smooth_ic(pts)
+    steps, back = 13, {}
+    for prec, tol in (("f32", TOL_F32), ("f64", TOL_F64)):
+        for wide_first in ("1", "0"):
+            monkeypatch.setenv("FEM_WIDE_FIRST", wide_first)
+            run = fdist.SingleRun(fa.Mesh(pts, tri), len(pts) // 820, prec, ksteps=5, dt_rule="stable")
+            om, pv = run.part.ordered, run.part.perm_v
+            assert np.array_equal(om.points[pv], pts)
+            ex = np.maximum(np.diff(om.topology()["rowptr"].astype(np.int64)) - 6, 0)
+            lead = all(np.all(np.diff(ex[run.part.node_parts[p]:run.part.node_parts[p + 1]]) <= 0) for p in range(run.part.n))
+            assert lead == (wide_first == "1") and ex.max() >= 4
+            n0, c0 = np.empty(om.V), np.empty(om.V)
+            n0[pv], c0[pv] = n_in, c_in
+            if prec == "f32":
+                n0, c0 = n0.astype(np.float32).astype(np.float64), c0.astype(np.float32).astype(np.float64)
+            run.plan.set_state(n0, c0)
+            run.run(steps)
+            n_gpu, c_gpu = run.plan.get_state()
+            st = ol.Stats(ol.Topology(om.V, om.tri), om.points, ol.F64)
+            n_ref, c_ref = st.step(n0, c0, run.dt, steps, run.model.as_array())
+            parity(n_gpu, c_gpu, n_ref, c_ref, tol, what="%s wide_first=%s" % (prec, wide_first))
+            assert not np.array_equal(n_gpu, n0)
+            back[(prec, wide_first)] = (n_gpu[pv], c_gpu[pv])
+        (na, ca), (nb, cb) = back[(prec, "1")], back[(prec, "0")]
+        parity(na, ca, nb, cb, tol, what="%s: the two numberings" % prec)

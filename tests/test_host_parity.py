@@ -505,3 +505,37 @@ def test_auto_partitioner_keeps_rcb_unless_coordinates_mislead():
     pv, pf, nparts, eparts, pts_o, tri_o = ol.partition_apply(m.V, pts, tri, auto, n)
     assert np.array_equal(part.perm_v, pv) and np.array_equal(part.perm_f, pf) and np.array_equal(part.node_parts, nparts)
     assert np.array_equal(part.element_parts, eparts) and np.array_equal(part.ordered.tri, tri_o)
+
+
+def test_wide_rows_first_numbering():
+    """fem_mesh_wide_rows_first (pre-pass of the partition stage for irregular meshes): a stable renumbering by the
+    number of row entries beyond 6, most first -- the same surface (every vertex keeps its point, faces keep their order
+    and corner order), the assembled operator rows merely relabelled; a mesh without wide rows is left alone; and after
+    the partition stage (stable inside a part, partitioning_common.cpp:112-139) the wide rows lead every part, widest first"""
+    pts, tri = fa.make_scanned_like(32, 0.1, seed=3)
+    m = fa.Mesh(pts, tri)
+    rp = m.topology()["rowptr"].astype(np.int64)
+    extra = np.maximum(np.diff(rp) - 6, 0)
+    m2, new = m.wide_rows_first(6)
+    order = np.argsort(-extra, kind="stable")
+    expect = np.empty(m.V, np.int64)
+    expect[order] = np.arange(m.V)
+    assert np.array_equal(new, expect)
+    assert np.array_equal(m2.points[new], pts) and np.array_equal(m2.tri, new[tri.astype(np.int64)].astype(np.uint32))
+    m.init_stats(fa.PREC_F64)
+    m2.init_stats(fa.PREC_F64)
+    s1, s2 = m.stats(), m2.stats()
+    assert np.array_equal(s2["wVtx"][new], s1["wVtx"]) and np.array_equal(s2["areaPerVtx"][new], s1["areaPerVtx"])
+    assert np.array_equal(s2["meshArea"], s1["meshArea"]) and s1["maxEdgeLen"] == s2["maxEdgeLen"]
+    same, none = fa.Mesh(*fa.make_icosphere(8, 0.1)).wide_rows_first(6)
+    assert none is None
+    # through the drivers' partition stage: inside every part the extras counts never increase
+    from fem_amd import dist as fdist
+    part = fdist._partition(m, 20)
+    om = part.ordered
+    assert np.array_equal(om.points[part.perm_v], pts)          # perm_v refers to the mesh the caller passed
+    ex = np.maximum(np.diff(om.topology()["rowptr"].astype(np.int64)) - 6, 0)
+    assert ex.max() > 0
+    for p in range(part.n):
+        seg = ex[part.node_parts[p]:part.node_parts[p + 1]]
+        assert np.all(np.diff(seg) <= 0)
