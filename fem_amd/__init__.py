@@ -425,20 +425,22 @@ class Plan:
     """Native plan: sliced-ELL operator + ping-pong state on the device."""
 
     def __init__(self, ordered, precision=PREC_F32, model=None, shard=None, part=None, ksteps=0, assemble=False,
-                 implicit=False):
+                 implicit=False, mixed=False):
         """ksteps > 0 (with part = the Partition of `ordered`): fused-tile layout, up to ksteps time
         steps per launch; otherwise the sliced-ELL layout, one step per launch.
         assemble=True keeps connectivity/positions on the device for fem_plan_assemble;
-        implicit=True (sliced-ELL plan of a whole mesh) enables run_imex."""
+        implicit=True (sliced-ELL plan of a whole mesh) enables run_imex;
+        mixed=True (fused fp64 plans): the reference's own precision mix -- fp64 state / Laplacian / update, fp32 gradient
+        branch (FEM_PLAN_MIXED_RECORDS)."""
         h = vp()
         mp = C.byref(model) if model is not None else None
         self.ksteps = ksteps
         self.F = ordered.F
-        if assemble or implicit:
+        if assemble or implicit or mixed:
             _check(lib.fem_plan_create_ex(ordered.h, C.c_int(part.n if part is not None else 0),
                                           _ptr(part.node_parts, u32p) if part is not None else None,
                                           shard.h if shard is not None else None, C.c_int(precision), mp,
-                                          C.c_int(ksteps), C.c_uint((1 if assemble else 0) | (2 if implicit else 0)), C.byref(h)))
+                                          C.c_int(ksteps), C.c_uint((1 if assemble else 0) | (2 if implicit else 0) | (4 if mixed else 0)), C.byref(h)))
             self.V = shard.n_local if shard is not None else ordered.V
         elif ksteps > 0:
             _check(lib.fem_plan_create_tiled(ordered.h, C.c_int(part.n), _ptr(part.node_parts, u32p),
@@ -504,8 +506,8 @@ class Plan:
                                       C.byref(rpt)))
         return dict(ksteps=k.value, ntiles=nt.value, max_local=ml.value, rows_loaded=rows.value,
                     threads=thr.value, rows_per_thread=rpt.value, groups_per_launch=max(1, self.persist_groups()),
-                    operator_records="12-byte (fp32 weight + 3 x 21-bit gradient coefficients, per-row scale)"
-                    if self.operator_format() == 1 else "4 scalars")
+                    operator_records={1: "12-byte (fp32 weight + 3 x 21-bit gradient coefficients, per-row scale)",
+                                      2: "20-byte (fp64 weight + 3 x fp32 gradient coefficients)"}.get(self.operator_format(), "4 scalars"))
 
     def pack_halo(self, dst_ptr, stream=None, which=0):
         """which = 0: from the current state buffer, 1: from the next one (see launch_tiles)"""

@@ -103,6 +103,7 @@ struct fem_plan {
   size_t entries = 0;
   DevBuf<fem_uint> slice_off, idx, send_idx;
   // fused-tile path (ksteps > 0): replaces the sliced-ELL arrays
+  bool mixed = false;               // FEM_PLAN_MIXED_RECORDS: fp64 weights + fp32 gradient coefficients in the fused tiles
   int ksteps = 0, tcfg = 0;
   // tile_step_persist_kernel: up to `persist` groups of k steps per launch (0: one launch per group; FEM_TILE_PERSIST,
   // else by tile count: persistRule); its control words, the per-tile "groups finished" flags, the tiles each tile waits for
@@ -247,6 +248,11 @@ static hipError_t launchTile(fem_plan *p, fem_uint first, fem_uint count, const 
     if (p->packed)
       kern = p->maxExtra ? (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 3, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 1, 1>)
                          : (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 3, 1> : tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 1, 1>);
+  }
+  if constexpr (sizeof(T) == 8 && (C == kDefaultTileCfg || C == kDefaultTileCfgWide)) {
+    if (p->mixed)
+      kern = p->maxExtra ? (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 3, 2> : tile_step_kernel<T, TPB, R, kTileW, MINW, 2, 1, 2>)
+                         : (pro >= 2 ? tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 3, 2> : tile_step_kernel<T, TPB, R, kTileW, MINW, 1, 1, 2>);
   }
   const size_t lds = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
                      (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
@@ -597,6 +603,8 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
     return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT needs a sliced-ELL plan (ksteps = 0)");
   if ((flags & FEM_PLAN_IMPLICIT) && (flags & FEM_PLAN_DEVICE_ASSEMBLY))
     return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_IMPLICIT takes the lumped masses from the host assembly; not combinable with FEM_PLAN_DEVICE_ASSEMBLY");
+  if ((flags & FEM_PLAN_MIXED_RECORDS) && (precision != FEM_PREC_F64 || ksteps < 1 || (flags & (FEM_PLAN_DEVICE_ASSEMBLY | FEM_PLAN_IMPLICIT))))
+    return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_MIXED_RECORDS needs a fused fp64 plan (ksteps >= 1) whose operator comes from the host assembly");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }
   if (!(model->nMax > -1.0)) return fail(FEM_ERR_INVALID, "fem_plan_create: nMax must be > -1");
@@ -787,7 +795,34 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
         p->tile_bytes += scaleWords * 4;                     // ... and one scale per row
       }
     }
-    if (!packed) uploadCoef(&p->tcoef, TL.coef);
+    if (flags & FEM_PLAN_MIXED_RECORDS) {
+      // The reference's own mix (src/common.h:7-11, FEM_common.cu:82-166: double2 state and Laplacian, float4 gradient
+      // vectors, float3 accumulators) on the fused tiles: per tile W * rows_pad weights in fp64, then W * rows_pad gradient
+      // coefficients of three floats, inside the block the four-double layout gives the tile (20 of its 32 bytes per
+      // entry are read); the extras of wide rows stay four doubles behind the block.
+      if (tcfg != kDefaultTileCfg && tcfg != kDefaultTileCfgWide) {
+        fem_plan_destroy(p);
+        return fail(FEM_ERR_INVALID, "fem_plan_create_ex: FEM_PLAN_MIXED_RECORDS runs on the two default register tiles (FEM_TILE_CONFIG 2 or 8)");
+      }
+      std::vector<double> mixedCoef(TL.coef);
+      uint64_t blockEntries = 0;
+      for (fem::uint t = 0; t < TL.ntiles; t++) blockEntries += (uint64_t)kTileW * TL.meta[16 * (size_t)t + 3];
+      fem::parallelFor(TL.ntiles, 64, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; t++) {
+          const size_t roff = TL.meta[16 * t + 2], rpad = TL.meta[16 * t + 3], n = (size_t)kTileW * rpad;
+          double *block = mixedCoef.data() + 4 * roff;
+          std::fill(block, block + 4 * n, 0.0);
+          float *g = reinterpret_cast<float *>(block + n);
+          for (size_t le = 0; le < n; le++) {
+            block[le] = TL.coef[4 * (roff + le)];
+            for (int d = 0; d < 3; d++) g[3 * le + d] = (float)TL.coef[4 * (roff + le) + 1 + d];
+          }
+        }
+      });
+      uploadCoef(&p->tcoef, mixedCoef);
+      p->mixed = true;
+      p->tile_bytes -= blockEntries * 12;
+    } else if (!packed) uploadCoef(&p->tcoef, TL.coef);
   } else {
     p->nslices = L.nslices; p->nblocks = (L.nslices + 3) / 4; p->entries = L.idx.size();
     ok(p->slice_off.alloc(L.slice_off.size())) && ok(p->slice_off.upload(L.slice_off.data())) &&
@@ -1307,6 +1342,24 @@ int fem_plan_download_coef(fem_plan *p, double *out) {
     }
     return FEM_OK;
   }
+  if (p->mixed) {                      // fp64 weights + fp32 gradient coefficients, widened
+    std::vector<double> raw(n);
+    std::vector<fem_uint> meta(16 * (size_t)p->ntiles);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(raw.data(), dev, 8 * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(meta.data(), p->tmeta.p, 4 * meta.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) out[i] = raw[i];       // extras of wide rows: four doubles as they are
+    for (size_t t = 0; t < p->ntiles; t++) {
+      const size_t roff = meta[16 * t + 2], rpad = meta[16 * t + 3], cnt = (size_t)kTileW * rpad;
+      const double *block = raw.data() + 4 * roff;
+      const float *g = reinterpret_cast<const float *>(block + cnt);
+      for (size_t le = 0; le < cnt; le++) {
+        out[4 * (roff + le)] = block[le];
+        for (int d = 0; d < 3; d++) out[4 * (roff + le) + 1 + d] = g[3 * le + d];
+      }
+    }
+    return FEM_OK;
+  }
   return p->precision == FEM_PREC_F32 ? downloadAs<float>(dev, n, out) : downloadAs<double>(dev, n, out);
   });
 }
@@ -1425,7 +1478,7 @@ int fem_plan_tile_info(const fem_plan *p, int *ksteps, fem_uint *ntiles, fem_uin
   return FEM_OK;
 }
 
-int fem_plan_operator_format(const fem_plan *p) { return p && p->packed ? 1 : 0; }
+int fem_plan_operator_format(const fem_plan *p) { return !p ? 0 : (p->packed ? 1 : (p->mixed ? 2 : 0)); }
 
 uint64_t fem_plan_operator_bytes(const fem_plan *p) {
   if (!p) return 0;

@@ -43,6 +43,7 @@ struct Options {
   double dtScale = 1.0;              // --dt-scale: time step = scale x 0.1 maxEdgeLen^2
   double watchdog = -1;              // --watchdog SECONDS (sharded runs; default 600, 0 = off): a run that has not finished by then reports where every rank is and exits 124
   bool inproc = false;
+  bool mixed = false;                // --mixed: fp64 plans in the reference's own mix (fp32 gradient branch), fused sharded runs
   std::string dump;                  // raw doubles: n[V] then c[V] of the final state, ordered numbering
 };
 
@@ -328,7 +329,8 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
       if (fem_shard_create(r.ordered, n, r.nodeParts.data(), rank, R, krings, &shard) != FEM_OK) { bail("shard", false); break; }
       stage[rank] = "set-up: plan";
       const int rc = o.imex > 0 ? fem_plan_create_ex(r.ordered, 0, nullptr, shard, o.precision, &model, 0, FEM_PLAN_IMPLICIT, &plan)
-                     : (o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), shard, o.precision, &model, o.fuse, &plan)
+                     : (o.fuse > 0 ? fem_plan_create_ex(r.ordered, n, r.nodeParts.data(), shard, o.precision, &model, o.fuse,
+                                                        o.mixed ? FEM_PLAN_MIXED_RECORDS : 0u, &plan)
                                    : fem_plan_create_shard(r.ordered, shard, o.precision, &model, &plan));
       if (rc != FEM_OK) { bail("plan", false); break; }
       fem_uint ownB = 0, ownE = 0, nLocal = 0, nSend = 0;
@@ -444,6 +446,7 @@ int usage() {
                "  --ranks N        native plan sharded over N ranks (threads; GPU = rank mod device count), halo exchange over\n"
                "                   RCCL every --rings K steps (default 2 x fuse); --transport inproc: device-to-device copies\n"
                "                   inside this process instead (all ranks may share one GPU); --f64: fp64 plans;\n"
+               "                   --mixed: fp64 plans in the reference's own precision mix (fp32 gradient branch; fused runs);\n"
                "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering);\n"
                "                   --imex ITERS: semi-implicit steps (diffusion by ITERS CG iterations, dot products all-reduced\n"
                "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2;\n"
@@ -466,6 +469,7 @@ int main(int argc, char **argv) {
     else if (a == "--native") o.native = true;
     else if (a == "--host-constants") o.hostConstants = true;
     else if (a == "--f64") o.precision = FEM_PREC_F64;
+    else if (a == "--mixed") { o.precision = FEM_PREC_F64; o.mixed = true; }
     else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out" ||
              a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--dt-scale" || a == "--watchdog") {
       const char *v = value();
@@ -491,7 +495,7 @@ int main(int argc, char **argv) {
     else return usage();
   }
   if (o.file.empty() || o.startN < 1 || o.endN < o.startN || o.maxIt < 1 || o.fuse < 0 || o.fuse > 8 || o.rowsPerPart < 1 ||
-      (o.hostConstants && !o.native) || o.ranks < 0 || o.ranks > 64 || o.krings < 0 || o.imex < 0 || (o.imex > 0 && o.ranks < 1) ||
+      (o.hostConstants && !o.native) || (o.mixed && (o.ranks < 1 || o.fuse < 1 || o.imex > 0)) || o.ranks < 0 || o.ranks > 64 || o.krings < 0 || o.imex < 0 || (o.imex > 0 && o.ranks < 1) ||
       !(o.dtScale > 0))
     return usage();
 

@@ -256,7 +256,8 @@ __device__ __forceinline__ void tile_body(
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
     const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile,
     uint maxLocal, uint maxExtra, int nsteps, const ModelT<T> &m) {
-  static_assert(!PK || sizeof(T) == 4, "packed operator records: fp32 plans");
+  static_assert(PK != 1 || sizeof(T) == 4, "packed operator records: fp32 plans");
+  static_assert(PK != 2 || sizeof(T) == 8, "mixed operator records: fp64 plans");
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   extern __shared__ __align__(16) unsigned char tile_smem[];
@@ -284,8 +285,10 @@ __device__ __forceinline__ void tile_body(
   // ghost ids, then the state gathers; the first wait is the one in front of the LDS writes.
   T4 cf[R][W];
   uint ix[R][W / 2];
-  uint pk[PK ? R : 1][PK ? W : 1][3];
-  float rs[PK ? R : 1];
+  uint pk[PK == 1 ? R : 1][PK == 1 ? W : 1][3];
+  float rs[PK == 1 ? R : 1];
+  double mw[PK == 2 ? R : 1][PK == 2 ? W : 1];        // PK == 2: Laplacian weights in fp64 ...
+  float mg[PK == 2 ? R : 1][PK == 2 ? W : 1][3];      // ... gradient coefficients in fp32
   constexpr int SU = 4;                                  // state slots per thread per pass
   uint gi[SU];
   auto loadGhostIds = [&](uint i0) {
@@ -343,7 +346,23 @@ __device__ __forceinline__ void tile_body(
     for (int w = 0; w < W / 2; w++)                      // ids < 4096: both halves scale
       ix[q][w] = (PRO == 3 ? __builtin_nontemporal_load(&tidx[w * rpad + r]) : tidx[w * rpad + r]) * (uint)sizeof(T2);
   }
-  if constexpr (PK) {
+  if constexpr (PK == 2) {
+    // the tile's block: W * rows_pad weights (fp64), then W * rows_pad gradient coefficients of three floats
+    const double *__restrict__ tw = reinterpret_cast<const double *>(tcoef);
+    const float *__restrict__ tg = reinterpret_cast<const float *>(tw + (size_t)W * rpad);
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const uint r = min(t + TPB * q, rpad - 1);
+#pragma unroll
+      for (int w = 0; w < W; w++) {
+        const double *wp = tw + (w * rpad + r);
+        const float *gp = tg + 3 * (size_t)(w * rpad + r);
+        mw[q][w] = PRO >= 2 ? __builtin_nontemporal_load(wp) : *wp;
+#pragma unroll
+        for (int d = 0; d < 3; d++) mg[q][w][d] = PRO >= 2 ? __builtin_nontemporal_load(gp + d) : gp[d];
+      }
+    }
+  } else if constexpr (PK == 1) {
     // scalar base of every entry slot + one 32-bit byte offset per row: the loads take the (SGPR base, VGPR offset)
     // form, no 64-bit address pair per load
 #pragma unroll
@@ -403,7 +422,7 @@ __device__ __forceinline__ void tile_body(
       if (i < mk) cur[i] = sv[u];
     }
   }
-  if constexpr (PK) {
+  if constexpr (PK == 1) {
     // decode the records into the register rows (all loads have landed: the state writes above waited for the
     // gathers, which were issued last)
 #pragma unroll
@@ -441,17 +460,33 @@ __device__ __forceinline__ void tile_body(
         }
 #pragma unroll
         for (int w = 0; w < W / 2; w++) asm volatile("" : "+v"(ix[q][w]));   // keep the unpacking in the loop, not in VGPRs
+        // PK == 2 (the reference's own mix, FEM_common.cu:99-150: double2 state and Laplacian, float4 gradient vectors
+        // and float3 accumulators): the differences and the Laplacian sums in fp64, the differences narrowed to fp32 for
+        // the gradient sums, which run in fp32 -- (gx, gy) of n, (gx, gy) of c and (gz of n, gz of c) as packed pairs
+        typedef float F2 __attribute__((ext_vector_type(2)));
+        F2 gn01 = {0, 0}, gc01 = {0, 0}, g2 = {0, 0};
+        T mlapn = 0, mlapc = 0;
 #pragma unroll
         for (int w = 0; w < W; w++) {
           const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);   // byte offset in the buffer
           const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
-          const T4 c = cf[q][w];
-          const V2 cxy = {c.x, c.y}, czw = {c.z, c.w};
           const T dn = f.x - self.x, dc = f.y - self.y;
-          an += cxy * dn; bn += czw * dn;
-          ac += cxy * dc; bc += czw * dc;
+          if constexpr (PK == 2) {
+            mlapn += mw[q][w] * dn; mlapc += mw[q][w] * dc;
+            const F2 cxy = {mg[q][w][0], mg[q][w][1]}, d2 = {(float)dn, (float)dc};
+            gn01 += cxy * d2.x; gc01 += cxy * d2.y; g2 += mg[q][w][2] * d2;
+          } else {
+            const T4 c = cf[q][w];
+            const V2 cxy = {c.x, c.y}, czw = {c.z, c.w};
+            an += cxy * dn; bn += czw * dn;
+            ac += cxy * dc; bc += czw * dc;
+          }
         }
         T lapn = an.x, gnx = an.y, gny = bn.x, gnz = bn.y, lapc = ac.x, gcx = ac.y, gcy = bc.x, gcz = bc.y;
+        if constexpr (PK == 2) {
+          lapn = mlapn; lapc = mlapc;
+          gnx = gn01.x; gny = gn01.y; gnz = g2.x; gcx = gc01.x; gcy = gc01.y; gcz = g2.y;
+        }
         if (X && xcnt) {                                 // entries W, W+1, ... of a wide row
           const uint xi = xs_info[r];
           for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {

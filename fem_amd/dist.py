@@ -51,7 +51,9 @@ class SingleRun:
         self.dt = dt
         self.seed = seed
         self.precision = precision
-        self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, part=self.part, ksteps=ksteps)
+        # "mixed": an fp64 plan in the reference's own precision mix (fp32 gradient branch, FEM_PLAN_MIXED_RECORDS)
+        self.plan = fa.Plan(om, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, part=self.part, ksteps=ksteps,
+                            mixed=precision == "mixed")
         n0, c0 = fa.initial_condition(om.V, seed)
         self.plan.set_state(n0, c0)
         self.V = om.V
@@ -90,7 +92,8 @@ class SingleRun:
         """what a PMC pass is valid for: kernel, precision, rows, fused depth, register tile, partition count"""
         ti = self.plan.tile_info()
         return "%s:%s:%d:k%d:%dx%d:p%d%s" % (self.kernel_name, self.precision, self.V, ti["ksteps"], ti["threads"],
-                                              ti["rows_per_thread"], self.part.n, ":rec12" if self.plan.operator_format() == 1 else "")
+                                              ti["rows_per_thread"], self.part.n,
+                                              {1: ":rec12", 2: ":rec20"}.get(self.plan.operator_format(), ""))
 
     def measured_traffic(self):
         return _recorded_traffic(self.traffic_key())
@@ -258,7 +261,7 @@ class HipShardStepper:
         self.torch = torch
         self.shard = shard
         self.plan = fa.Plan(ordered, fa.PREC_F32 if precision == "f32" else fa.PREC_F64, model, shard=shard,
-                            part=part, ksteps=ksteps, assemble=assemble)
+                            part=part, ksteps=ksteps, assemble=assemble, mixed=precision == "mixed")
         self.plan.set_state(n_loc, c_loc)
         self.dtype = torch.float32 if precision == "f32" else torch.float64
         self.typestr = "<f4" if precision == "f32" else "<f8"

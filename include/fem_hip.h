@@ -284,6 +284,12 @@ int fem_plan_create_tiled(const fem_mesh *ordered, int n, const fem_uint *node_p
  * ksteps = 0: sliced-ELL layout; n/node_parts may then be 0/NULL. */
 #define FEM_PLAN_DEVICE_ASSEMBLY 1u
 #define FEM_PLAN_IMPLICIT 2u          /* sliced-ELL plan (whole mesh or a shard): enables fem_plan_run_imex[_sharded] (not with DEVICE_ASSEMBLY) */
+/* fused fp64 plans (precision FEM_PREC_F64, ksteps >= 1, host assembly) in the reference's OWN precision mix: state,
+ * differences, Laplacian weights and sums, and the update in fp64 (FN_TYPE = double, src/common.h:7-11; double2 fn and
+ * fp64 ELL weights, FEM_common.cu:135-165), the gradient branch in fp32 (float4 grads, differences narrowed to float,
+ * float3 accumulators: FEM_common.cu:99-132,153-158).  The operator stream is then 20 bytes per entry instead of 32
+ * (fem_plan_operator_format = 2).  State buffers, set/get, halo packing: exactly as for any fp64 plan. */
+#define FEM_PLAN_MIXED_RECORDS 4u
 int fem_plan_create_ex(const fem_mesh *ordered, int n, const fem_uint *node_parts,
                        const fem_shard *shard, int precision, const fem_model *model, int ksteps,
                        unsigned flags, fem_plan **out);
@@ -401,7 +407,8 @@ uint64_t fem_plan_operator_bytes(const fem_plan *p);
  *     stay four floats).  Default for fp32 plans, fused or single-step, whose operator comes from the host assembly
  *     and that are not FEM_PLAN_IMPLICIT;
  *     FEM_TILE_PACKED=0 in the environment at plan creation keeps format 0.  fem_plan_download_coef returns the
- *     decoded values either way. */
+ *     decoded values either way;
+ * 2 = fused fp64 plans created with FEM_PLAN_MIXED_RECORDS: w in fp64, Cx, Cy, Cz in fp32 (20 bytes per entry). */
 int fem_plan_operator_format(const fem_plan *p);
 
 /* ------------------------------------------------------------------ */

@@ -54,10 +54,11 @@ def run_fem(cmd, env=None):
     return res
 
 
-def run_ranks(path, tmp_path, ranks, fuse, rings, transport, overlap=None, f64=True):
+def run_ranks(path, tmp_path, ranks, fuse, rings, transport, overlap=None, f64=True, mixed=False):
     dump = str(tmp_path / "state.bin")
     cmd = [FEM_RUN, path, "--ranks", str(ranks), "-n", str(NPARTS), "--fuse", str(fuse), "--rings", str(rings),
-           "--iterations", str(ITER), "--seed", "3", "--transport", transport, "--dump", dump] + (["--f64"] if f64 else [])
+           "--iterations", str(ITER), "--seed", "3", "--transport", transport, "--dump", dump] + (
+               ["--mixed"] if mixed else (["--f64"] if f64 else []))
     env = dict(os.environ)
     env.pop("FEM_OVERLAP", None)
     if overlap is not None:
@@ -103,6 +104,17 @@ def test_fp32_shards_against_the_f64_oracle(sphere_off, reference, tmp_path, ran
     assert "Ranks: %d (in-process copies" % ranks in out
     parity(n, c, n_ref, c_ref, 1e-5)
     assert rel_l2(n, n_ref) > 1e-12                 # fp32 did run (an f64 plan would be at 1e-14)
+
+
+def test_mixed_record_shards_against_the_f64_oracle(sphere_off, reference, tmp_path):
+    """fp64 shard plans in the reference's own precision mix (fem_run --mixed: FEM_PLAN_MIXED_RECORDS in boundary, ghost and
+    interior tiles), three ranks with real neighbours: between the fp64 plans (1e-14) and the fp32 ones (1e-7 of the
+    deviation) -- observed n 2e-9 of the deviation"""
+    part, (n_ref, c_ref) = reference
+    n, c, out = run_ranks(sphere_off, tmp_path, 3, 4, 8, "inproc", None, mixed=True)
+    assert "Ranks: 3 (in-process copies" in out
+    parity(n, c, n_ref, c_ref, 1e-9, tol_dev=1e-7)
+    assert rel_l2(n, n_ref) > 1e-13                 # the fp32 gradient branch did run (an f64 plan would be at 1e-14)
 
 
 def test_rccl_refuses_more_ranks_than_gpus(sphere_off):

@@ -708,3 +708,47 @@ def test_wide_rows_first_numbering_on_the_fused_plan(monkeypatch):
             back[(prec, wide_first)] = (n_gpu[pv], c_gpu[pv])
         (na, ca), (nb, cb) = back[(prec, "1")], back[(prec, "0")]
         parity(na, ca, nb, cb, tol, what="%s: the two numberings" % prec)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,ksteps", [(8, 7), (2, 5)])
+def test_mixed_records_plan(cfg, ksteps, monkeypatch):
+    """FEM_PLAN_MIXED_RECORDS: a fused fp64 plan in the reference's own precision mix (fp64 state, differences, Laplacian
+    and update; gradient coefficients, narrowed differences and gradient sums in fp32: FEM_common.cu:99-158).  The
+    downloaded operator is the fp64 plan's with the three gradient coefficients of the register rows rounded to fp32
+    (weights and the extras of wide rows bit-equal); the run stays within 1e-9 / 1e-7 (fields / deviation) of the f64
+    oracle and of the oracle's MIXED CPUrun, two orders closer than the fp32 plan; other plan kinds refuse the flag.
+    Observed against the f64 oracle: fields 9e-11, deviation 1.7e-9 on the sphere (random IC), 4e-15 / 2e-12 on the
+    irregular mesh (smooth IC); fp32 plan: 4e-9 / 1e-7, fp64 plan: 1e-14 / 1e-12."""
+    monkeypatch.setenv("FEM_TILE_CONFIG", str(cfg))
+    from helpers import Case
+    steps = 2 * ksteps + 3
+    for (pts, tri), regular in ((fa.make_icosphere(64, 0.1), True),
+                                (fa.make_scanned_like(40, 0.1, seed=3, high_valence_fraction=0.01), False)):
+        case = Case(pts, tri, max(2, len(pts) // _TIMED_N0[cfg][ksteps]))
+        case.mesh.init_stats(fa.PREC_F64)
+        st = case.ostats(ol.F64)
+        dt = case.dt if regular else min(case.dt, stable_dt(st, case.model))
+        full = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+        mixed = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps, mixed=True)
+        assert mixed.operator_format() == 2 and full.operator_format() == 0
+        assert mixed.operator_bytes() < 0.75 * full.operator_bytes()
+        cf, cm = full.coef().reshape(-1, 4), mixed.coef().reshape(-1, 4)
+        assert np.array_equal(cm[:, 0], cf[:, 0])
+        rounded = cf[:, 1:].astype(np.float32).astype(np.float64)
+        same = np.all(cm[:, 1:] == rounded, axis=1) | np.all(cm[:, 1:] == cf[:, 1:], axis=1)     # register rows | extras
+        assert same.all() and (np.all(cm[:, 1:] == cf[:, 1:], axis=1).mean() < 0.9)
+        n0, c0 = (case.n0, case.c0) if regular else smooth_ic(case.pts)
+        mixed.set_state(n0, c0)
+        mixed.run(steps, dt, case.model)
+        n_gpu, c_gpu = mixed.get_state()
+        n_ref, c_ref = st.step(n0, c0, dt, steps, case.model.as_array())
+        e = parity(n_gpu, c_gpu, n_ref, c_ref, 1e-9, tol_dev=1e-7, what="mixed vs f64 oracle")
+        n_mx, c_mx = case.ostats(ol.MIXED).step(n0, c0, dt, steps, case.model.as_array())
+        # (the MIXED oracle also assembles from fp32 geometry, mesh_function.cpp:119-121: an operator 1e-7 away)
+        e2 = parity(n_gpu, c_gpu, n_mx, c_mx, 1e-7, tol_dev=1e-5 if regular else 2e-4, what="mixed vs MIXED oracle")
+        assert not np.array_equal(n_gpu, n0)
+        print("mixed records, regular=%s: vs f64 oracle %s, vs MIXED oracle %s" % (regular, e, e2))
+    for kw in (dict(precision=fa.PREC_F32, ksteps=ksteps), dict(precision=fa.PREC_F64, ksteps=0)):
+        with pytest.raises(fa.FemError):
+            fa.Plan(case.mesh, kw["precision"], part=case.part, ksteps=kw["ksteps"], mixed=True)
