@@ -1,7 +1,8 @@
 #!/bin/bash
-# usage (build machine, after tools/r03_profiles.sh has run on the GPU box): bash tools/r03_summarize.sh
-# condenses gpurun_out/r03_* into profiles/ and records each traffic figure under its run's own traffic key
-for tag in r03_sphere16m_fused7_rec12 r03_scan8m_fused5_rec12 r03_deform4m r03_sphere16m_sell_rec12 r03_sphere1m_persist; do
+# usage (build machine, after tools/r03_profiles.sh / r03b_profiles.sh has run on the GPU box): bash tools/r03_summarize.sh [r03|r03b]
+# condenses gpurun_out/<prefix>_* into profiles/ and records each traffic figure under its run's own traffic key
+P=${1:-r03}
+for tag in ${P}_sphere16m_fused7_rec12 ${P}_sphere16m_fused7_mixed ${P}_scan8m_fused5_rec12 ${P}_deform4m ${P}_sphere16m_sell_rec12 ${P}_sphere1m_persist; do
   d=gpurun_out/$tag
   [ -s $d/bench_under_rocprof.json ] || { echo "missing $d"; continue; }
   key=$(python3 -c "import json,sys; print(json.load(open('$d/bench_under_rocprof.json'))['roofline']['traffic_key'])")
@@ -9,5 +10,5 @@ for tag in r03_sphere16m_fused7_rec12 r03_scan8m_fused5_rec12 r03_deform4m r03_s
   python3 tools/summarize_prof.py $tag $d/stats $d/fetch $d/write "$key" > /dev/null || echo "summary of $tag failed"
   echo "$tag -> $key"
 done
-cp gpurun_out/r03_sphere16m_fused7_rec12_sq_counters.txt profiles/ 2>/dev/null
+cp gpurun_out/${P}_sphere16m_fused7_rec12_sq_counters.txt profiles/ 2>/dev/null
 python3 -c "import json; print(json.dumps(json.load(open('profiles/traffic.json')), indent=1)[:3000])"
