@@ -27,7 +27,10 @@ pytestmark = pytest.mark.gpu
 # drop-in step() against the oracle's MIXED mode: the reference keeps the half-edge gradients and their products in fp32
 # (float4 he_grads, FEM_common.cu:104-132), so the two sides agree only up to how the compiler contracts those fp32
 # multiply-adds (nvcc and hipcc both do by default; the oracle is C without contraction): observed 2e-10 .. 1.4e-8
-# (the largest on the single-triangle mesh, where nothing averages out)
+# (the largest on the single-triangle mesh, where nothing averages out).  Measured in round 3: with `#pragma clang fp
+# contract(off)` inside ref_step_kernel the 100-step figures on the nu=32 sphere / the strip are 1.26e-11 / 7.0e-12 against
+# 1.43e-11 / 1.41e-11 with the default contraction, at the same speed -- what is left is the order of the fp32 corner sums,
+# so the pragma was not adopted (it would only pin the kernel's bits against future flag changes).
 TOL_REF = 3e-8
 TOL_F64 = 1e-11
 TOL_F32 = 1e-5
