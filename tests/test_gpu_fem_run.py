@@ -107,3 +107,25 @@ def test_ply_input_and_partition_range(tmp_path):
     best = re.search(r"Best time with (\d+) partitions is (\S+)!", res.stdout)
     times = {int(l[1]): float(l[3]) for l in lines}
     assert best and int(best.group(1)) == min(times, key=times.get)
+
+
+@pytest.mark.gpu
+def test_native_plan_numbers_wide_rows_first(tmp_path):
+    """an irregular mesh (valences up to 16) through `fem_run --native`: the driver numbers the rows of more than 6 entries
+    first (fem_mesh_wide_rows_first, as fem_amd/dist.py:_partition does), says so with -v, and the fused plan on the
+    renumbered mesh passes the program's own check against its fp64 host steps; a regular sphere is left as it is"""
+    pts, tri = fa.make_scanned_like(24, 0.1, seed=3, high_valence_fraction=0.01)
+    path = str(tmp_path / "scan.off")
+    fa.off_write(path, pts, tri)
+    res = run(path, "--native", "-v", "--iterations", "20", "--rows", "400", "--fuse", "4", "--dt-scale", "0.2")
+    assert res.returncode == 0, res.stdout + res.stderr
+    m = re.search(r"(\d+) rows of more than 6 entries: numbered first", res.stdout)
+    val = np.bincount(tri.ravel().astype(np.int64), minlength=len(pts))
+    assert m and int(m.group(1)) == int((val > 6).sum())
+    r = ROUND.search(res.stdout)
+    assert r and float(r.group(3)) < 2e-7 and float(r.group(5)) < 2e-7
+    sp, st = fa.make_icosphere(8, 0.1)
+    path2 = str(tmp_path / "sphere.off")
+    fa.off_write(path2, sp, st)
+    res2 = run(path2, "--native", "-v", "--iterations", "10", "--rows", "200")
+    assert res2.returncode == 0 and "0 rows of more than 6 entries" in res2.stdout and "numbered first" not in res2.stdout
