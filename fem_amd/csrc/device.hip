@@ -812,10 +812,11 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
           const size_t roff = TL.meta[16 * t + 2], rpad = TL.meta[16 * t + 3], n = (size_t)kTileW * rpad;
           double *block = mixedCoef.data() + 4 * roff;
           std::fill(block, block + 4 * n, 0.0);
-          float *g = reinterpret_cast<float *>(block + n);
+          unsigned char *g = reinterpret_cast<unsigned char *>(block + n);      // the float triples, written bytewise
           for (size_t le = 0; le < n; le++) {
             block[le] = TL.coef[4 * (roff + le)];
-            for (int d = 0; d < 3; d++) g[3 * le + d] = (float)TL.coef[4 * (roff + le) + 1 + d];
+            const float c3[3] = {(float)TL.coef[4 * (roff + le) + 1], (float)TL.coef[4 * (roff + le) + 2], (float)TL.coef[4 * (roff + le) + 3]};
+            memcpy(g + 12 * le, c3, 12);
           }
         }
       });
@@ -1352,10 +1353,12 @@ int fem_plan_download_coef(fem_plan *p, double *out) {
     for (size_t t = 0; t < p->ntiles; t++) {
       const size_t roff = meta[16 * t + 2], rpad = meta[16 * t + 3], cnt = (size_t)kTileW * rpad;
       const double *block = raw.data() + 4 * roff;
-      const float *g = reinterpret_cast<const float *>(block + cnt);
+      const unsigned char *g = reinterpret_cast<const unsigned char *>(block + cnt);
       for (size_t le = 0; le < cnt; le++) {
+        float c3[3];
+        memcpy(c3, g + 12 * le, 12);
         out[4 * (roff + le)] = block[le];
-        for (int d = 0; d < 3; d++) out[4 * (roff + le) + 1 + d] = g[3 * le + d];
+        for (int d = 0; d < 3; d++) out[4 * (roff + le) + 1 + d] = c3[d];
       }
     }
     return FEM_OK;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (build machine, after tools/r03_profiles.sh / r03b_profiles.sh has run on the GPU box): bash tools/r03_summarize.sh [r03|r03b]
 # condenses gpurun_out/<prefix>_* into profiles/ and records each traffic figure under its run's own traffic key
+# (gpurun MERGES into gpurun_out/: delete gpurun_out/<prefix>_* before a repeated profile run, or an older pass's files may be the ones read)
 P=${1:-r03}
 for tag in ${P}_sphere16m_fused7_rec12 ${P}_sphere16m_fused7_mixed ${P}_scan8m_fused5_rec12 ${P}_deform4m ${P}_sphere16m_sell_rec12 ${P}_sphere1m_persist; do
   d=gpurun_out/$tag
