@@ -218,11 +218,13 @@ double gpuRun(int n, const Options &o, const fem_model &model, const Run &r) {
   return usPerStep;
 }
 
-// the same protocol on the native fp32 plan (fused tiles; fuse = 0: sliced ELL)
+// the same protocol on the native plan (fused tiles; fuse = 0: sliced ELL): fp32, --f64, or --mixed (fp64 in the reference's
+// own precision mix, fused tiles only)
 double nativeRun(int n, const Options &o, const fem_model &model, const Run &r) {
   fem_plan *plan = nullptr;
-  const int rc = o.fuse > 0 ? fem_plan_create_tiled(r.ordered, n, r.nodeParts.data(), nullptr, FEM_PREC_F32, &model, o.fuse, &plan)
-                            : fem_plan_create(r.ordered, FEM_PREC_F32, &model, &plan);
+  const int rc = o.fuse > 0 ? fem_plan_create_ex(r.ordered, n, r.nodeParts.data(), nullptr, o.precision, &model, o.fuse,
+                                                 o.mixed ? FEM_PLAN_MIXED_RECORDS : 0u, &plan)
+                            : fem_plan_create(r.ordered, o.precision, &model, &plan);
   if (rc == FEM_ERR_LIMIT) { std::printf("%s\n", fem_error_detail()); return -2; }
   if (!ok(rc, "plan")) return -1;
   double usPerStep = -1;
@@ -447,6 +449,7 @@ int usage() {
                "                   RCCL every --rings K steps (default 2 x fuse); --transport inproc: device-to-device copies\n"
                "                   inside this process instead (all ranks may share one GPU); --f64: fp64 plans;\n"
                "                   --mixed: fp64 plans in the reference's own precision mix (fp32 gradient branch; fused runs);\n"
+               "                   (--f64 and --mixed also without --ranks: the native single-GPU plan in that precision)\n"
                "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering);\n"
                "                   --imex ITERS: semi-implicit steps (diffusion by ITERS CG iterations, dot products all-reduced\n"
                "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2;\n"
@@ -468,8 +471,8 @@ int main(int argc, char **argv) {
     else if (a == "-v") o.verbose = true;
     else if (a == "--native") o.native = true;
     else if (a == "--host-constants") o.hostConstants = true;
-    else if (a == "--f64") o.precision = FEM_PREC_F64;
-    else if (a == "--mixed") { o.precision = FEM_PREC_F64; o.mixed = true; }
+    else if (a == "--f64") { o.precision = FEM_PREC_F64; o.native = true; }
+    else if (a == "--mixed") { o.precision = FEM_PREC_F64; o.mixed = true; o.native = true; }
     else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out" ||
              a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--dt-scale" || a == "--watchdog") {
       const char *v = value();
@@ -495,7 +498,7 @@ int main(int argc, char **argv) {
     else return usage();
   }
   if (o.file.empty() || o.startN < 1 || o.endN < o.startN || o.maxIt < 1 || o.fuse < 0 || o.fuse > 8 || o.rowsPerPart < 1 ||
-      (o.hostConstants && !o.native) || (o.mixed && (o.ranks < 1 || o.fuse < 1 || o.imex > 0)) || o.ranks < 0 || o.ranks > 64 || o.krings < 0 || o.imex < 0 || (o.imex > 0 && o.ranks < 1) ||
+      (o.hostConstants && !o.native) || (o.mixed && (!o.native || o.fuse < 1 || o.imex > 0)) || (o.precision == FEM_PREC_F64 && !o.native) || o.ranks < 0 || o.ranks > 64 || o.krings < 0 || o.imex < 0 || (o.imex > 0 && o.ranks < 1) ||
       !(o.dtScale > 0))
     return usage();
 

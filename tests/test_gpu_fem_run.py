@@ -129,3 +129,16 @@ def test_native_plan_numbers_wide_rows_first(tmp_path):
     fa.off_write(path2, sp, st)
     res2 = run(path2, "--native", "-v", "--iterations", "10", "--rows", "200")
     assert res2.returncode == 0 and "0 rows of more than 6 entries" in res2.stdout and "numbered first" not in res2.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag,bar", [("--f64", 1e-10), ("--mixed", 2e-10)])
+def test_native_plan_in_fp64_and_in_the_reference_mix(sphere_off, flag, bar):
+    """`fem_run --f64` / `--mixed` without --ranks: the native single-GPU fused plan in fp64, and in the reference's own
+    precision mix (FEM_PLAN_MIXED_RECORDS), each passing the program's check against its host steps at its own level.  The
+    host steps are the reference's CPUrun, whose gradient dot product is fp32 (main.cpp:647-665), so even the fp64 plan
+    differs from them: mean error per vertex of n after two steps 2.6e-11 (fp64), 5.4e-11 (mixed), 6.4e-9 (fp32 plan)"""
+    res = run(sphere_off[0], flag, "-v", "--iterations", "20", "--rows", "400", "--fuse", "4")
+    assert res.returncode == 0, res.stdout + res.stderr
+    m = ROUND.search(res.stdout)
+    assert m and float(m.group(3)) < bar and float(m.group(5)) < bar, res.stdout
