@@ -576,6 +576,14 @@ class Plan:
         mp = C.byref(model) if model is not None else None
         _check(lib.fem_plan_run_imex(self.h, C.c_int(nsteps), C.c_double(dt), mp, C.c_int(cg_iterations), vp(stream or 0)))
 
+    def run_imex_fused(self, nsteps, dt, model=None, rel_tol=1e-6, stream=None):
+        """semi-implicit steps on a fused-tile plan: Chebyshev iteration, ksteps iterations per launch (fem_plan_run_imex_fused)"""
+        mp = C.byref(model) if model is not None else None
+        _check(lib.fem_plan_run_imex_fused(self.h, C.c_int(nsteps), C.c_double(dt), mp, C.c_double(rel_tol), vp(stream or 0)))
+
+    def imex_fused_iterations(self):
+        return int(lib.fem_plan_imex_fused_iterations(self.h))
+
     def imex_tolerance(self, rel_tol):
         """residual-based stop of the CG solves (0 = fixed iteration count)"""
         _check(lib.fem_plan_imex_tolerance(self.h, C.c_double(rel_tol)))

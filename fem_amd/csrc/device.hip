@@ -131,6 +131,11 @@ struct fem_plan {
   double *maxedge = nullptr, *blockmax = nullptr;
   // semi-implicit stepping (FEM_PLAN_IMPLICIT): lumped mass and row sums of w per row; CG work vectors
   bool can_imex = false, imex_ready = false;
+  // semi-implicit steps on the fused tiles (fem_plan_run_imex_fused): largest row sum of the Laplacian weights (spectrum
+  // bound), the weights alone in tile order, right-hand side, second iterate buffer, the two direction buffers
+  double wsum_max = 0;
+  void *cb_tw = nullptr, *cb_b = nullptr, *cb_x = nullptr, *cb_d[2] = {nullptr, nullptr};
+  int cheb_iters = 0;
   double imex_tol = 0;              // fem_plan_imex_tolerance: relative residual at which a solve stops (0: fixed iteration count)
   void *mass = nullptr, *wsum = nullptr, *ix_w = nullptr, *ix_r = nullptr, *ix_p = nullptr, *ix_q = nullptr;
   double *ix_partial = nullptr, *ix_sc = nullptr;
@@ -403,6 +408,97 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
   return FEM_OK;
 }
 
+// Semi-implicit steps on a fused-tile plan (kernels_implicit.hpp, second half): right-hand side by one pass of the tile
+// kernel, then ceil(N / k) launches of k Chebyshev iterations each, N from the spectrum bounds and the tolerance.
+template <typename T, int C>
+static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *model, double tol, hipStream_t st) {
+  typedef typename Vec<T>::t2 T2;
+  typedef typename Vec<T>::t4 T4;
+  constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
+  constexpr int MINW = sizeof(T) == 4 ? kTileCfgs[C].minw : 2;
+  const size_t V = p->V;
+  if (!p->cb_tw) {
+    void *bufs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    const size_t sizes[5] = {sizeof(T) * std::max<size_t>(p->tile_entries, 1), sizeof(T2) * V, sizeof(T2) * V, sizeof(T2) * V, sizeof(T2) * V};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && e == hipSuccess; i++) e = hipMalloc(&bufs[i], sizes[i]);
+    if (e == hipSuccess) e = hipMemsetAsync(bufs[3], 0, sizes[3], st);
+    if (e == hipSuccess) e = hipMemsetAsync(bufs[4], 0, sizes[4], st);
+    if (e != hipSuccess) {
+      for (void *q : bufs) if (q) (void)hipFree(q);
+      return fail(FEM_ERR_DEVICE, "fem_plan_run_imex_fused: work vectors", e);
+    }
+    hipLaunchKernelGGL(tile_weights_kernel<T>, dim3(p->ntiles), dim3(256), 0, st, (const void *)p->tcoef, (T *)bufs[0], p->tmeta.p,
+                       (fem_uint)kTileW, p->packed ? 1 : (p->mixed ? 2 : 0));
+    p->cb_tw = bufs[0]; p->cb_b = bufs[1]; p->cb_x = bufs[2]; p->cb_d[0] = bufs[3]; p->cb_d[1] = bufs[4];
+  }
+  // iterations for the tolerance: the Chebyshev error bound 2 rho^N / (1 + rho^2N) <= tol on the wider of the two spectra
+  const double Df[2] = {model->D, 1.0};
+  double theta[2], delta[2];
+  int N = 1;
+  for (int f = 0; f < 2; f++) {
+    const double hi = 1.0 + 2.0 * dt * Df[f] * p->wsum_max * 1.001;
+    theta[f] = 0.5 * (hi + 1.0); delta[f] = 0.5 * (hi - 1.0);
+    const double kappa = hi, rho = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
+    if (rho > 0) N = std::max(N, (int)std::ceil(std::log(2.0 / tol) / -std::log(rho)));
+  }
+  N = std::min(N, 100000);
+  p->cheb_iters = N;
+  const int k = p->ksteps, launches = (N + k - 1) / k;
+  const ModelT<T> m = {(T)(model->nMax - p->base_n), (T)model->D, (T)model->r, (T)model->alpha, (T)model->S, (T)dt, (T)p->base_n,
+                       (T)(1.0 / (1.0 + p->base_n))};
+  auto rhsKern = [&]() {
+    if constexpr (sizeof(T) == 4)
+      return p->packed ? (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 1> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 1>)
+                       : (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 0> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 0>);
+    else
+      return p->mixed ? (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 2> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 2>)
+                      : (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 0> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 0>);
+  }();
+  auto chebKern = tile_cheb_kernel<T, TPB, R, kTileW, MINW>;
+  const size_t ldsRhs = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
+                        (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
+  const size_t ldsCheb = 2 * (size_t)p->maxLocal * sizeof(T2);
+  if (ldsRhs > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rhsKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRhs));
+  if (ldsCheb > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)chebKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsCheb));
+  for (int s = 0; s < nsteps; s++) {
+    const T2 *u = (const T2 *)p->state[p->cur];
+    T2 *out = (T2 *)p->state[p->cur ^ 1];
+    hipLaunchKernelGGL(rhsKern, dim3(p->ntiles), dim3(TPB), ldsRhs, st, u, (T2 *)p->cb_b, p->tmeta.p, p->tghost.p, p->tidx2.p,
+                       (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra, m);
+    // x_0 = b; the iterate alternates between two buffers so that the last launch writes the plan's next state
+    double rho[2] = {delta[0] / theta[0], delta[1] / theta[1]};
+    const T2 *xin = (const T2 *)p->cb_b;
+    int it = 0;
+    for (int l = 0; l < launches; l++) {
+      T2 *xout = ((launches - 1 - l) & 1) ? (T2 *)p->cb_x : out;
+      const int nit = std::min(k, N - it);
+      ChebArgs<T> a;
+      a.dtDn = (T)(dt * model->D); a.dtDc = (T)dt; a.first = l == 0;
+      for (int j = 0; j < 8; j++) { a.c1n[j] = a.c2n[j] = a.c1c[j] = a.c2c[j] = 0; }
+      for (int j = 0; j < nit; j++, it++) {
+        for (int f = 0; f < 2; f++) {
+          double c1, c2;
+          if (it == 0) { c1 = 0; c2 = 1.0 / theta[f]; }
+          else {
+            const double sigma = theta[f] / delta[f], next = 1.0 / (2.0 * sigma - rho[f]);
+            c1 = next * rho[f]; c2 = 2.0 * next / delta[f];
+            rho[f] = next;
+          }
+          (f == 0 ? a.c1n : a.c1c)[j] = (T)c1; (f == 0 ? a.c2n : a.c2c)[j] = (T)c2;
+        }
+      }
+      hipLaunchKernelGGL(chebKern, dim3(p->ntiles), dim3(TPB), ldsCheb, st, xin, xout, (const T2 *)p->cb_b, (const T2 *)p->cb_d[l & 1],
+                         (T2 *)p->cb_d[(l & 1) ^ 1], p->tmeta.p, p->tghost.p, p->tidx2.p, (const T *)p->cb_tw, p->ntiles, p->maxLocal, nit, a);
+      xin = xout;
+    }
+    hipLaunchKernelGGL(imex_clamp_kernel<T>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, out, p->V, (T)p->base_n, (T)p->base_c);
+    p->cur ^= 1;
+  }
+  HIP_TRY(hipGetLastError());
+  return FEM_OK;
+}
+
 extern "C" {
 
 #ifndef FEM_KERNEL_BUILD
@@ -587,6 +683,7 @@ void fem_plan_destroy(fem_plan *p) {
   p->tri0.release(); p->tri1.release(); p->tri2.release(); p->topo.release(); p->rowg.release();
   for (void *q : {p->pos, p->pos0, p->rec, (void *)p->maxedge, (void *)p->blockmax}) if (q) (void)hipFree(q);
   for (void *q : {p->mass, p->wsum, p->ix_w, p->ix_r, p->ix_p, p->ix_q, (void *)p->ix_partial, (void *)p->ix_sc}) if (q) (void)hipFree(q);
+  for (void *q : {p->cb_tw, p->cb_b, p->cb_x, p->cb_d[0], p->cb_d[1]}) if (q) (void)hipFree(q);
   if (p->tcoef) (void)hipFree(p->tcoef);
   if (p->rscale) (void)hipFree(p->rscale);
   if (p->coef) (void)hipFree(p->coef);
@@ -687,6 +784,11 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   (void)hipGetDevice(&p->device);
   p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
   p->precision = precision; p->V = op.V;
+  for (fem::uint r = 0; r < op.V; r++) {
+    double ws = 0;
+    for (fem::uint q = op.rowptr[r]; q < op.rowptr[r + 1]; q++) ws += op.coef[4 * (size_t)q];
+    if (ws > p->wsum_max) p->wsum_max = ws;
+  }
   if (const char *e = getenv("FEM_TILE_PROLOGUE")) p->prologue = std::min(3, std::max(0, atoi(e)));
   if (const char *e = getenv("FEM_SELL_NT")) p->sell_nt = atoi(e) != 0;
   if (const char *e = getenv("FEM_TILE_PERSIST")) p->persist = std::max(0, atoi(e));      // 0 off, n: n groups per launch, whatever the size
@@ -1150,6 +1252,26 @@ int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model
                                       : runImex<double>(p, nsteps, dt, model, cg_iterations, (hipStream_t)stream);
   });
 }
+
+int fem_plan_run_imex_fused(fem_plan *p, int nsteps, double dt, const fem_model *model, double rel_tol, void *stream) {
+  return fem::guarded("fem_plan_run_imex_fused", [&]() -> int {
+  if (!p || nsteps < 0 || !(dt > 0) || !(rel_tol > 0) || rel_tol >= 1) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: bad argument (0 < rel_tol < 1)");
+  if (p->ksteps < 1 || (p->tcfg != kDefaultTileCfg && p->tcfg != kDefaultTileCfgWide) || p->can_assemble)
+    return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: needs a fused-tile plan (fem_plan_create_tiled) on a default register tile, operator from the host assembly");
+  if (p->maxExtra) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: rows of more than 6 entries are not supported (use fem_plan_run_imex)");
+  if (p->nGhost || p->nBoundary) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: whole-mesh plans only");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  hipStream_t st = (hipStream_t)stream;
+  if (p->precision == FEM_PREC_F32)
+    return p->tcfg == kDefaultTileCfg ? runImexFused<float, kDefaultTileCfg>(p, nsteps, dt, model, rel_tol, st)
+                                      : runImexFused<float, kDefaultTileCfgWide>(p, nsteps, dt, model, rel_tol, st);
+  return p->tcfg == kDefaultTileCfg ? runImexFused<double, kDefaultTileCfg>(p, nsteps, dt, model, rel_tol, st)
+                                    : runImexFused<double, kDefaultTileCfgWide>(p, nsteps, dt, model, rel_tol, st);
+  });
+}
+
+int fem_plan_imex_fused_iterations(const fem_plan *p) { return p ? p->cheb_iters : 0; }
 
 int fem_plan_run_imex_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, fem_uint n_own,
                               const fem_imex_comm *comm, void *stream) {

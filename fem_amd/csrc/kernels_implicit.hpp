@@ -200,3 +200,110 @@ __global__ __launch_bounds__(256) void imex_clamp_kernel(typename Vec<T>::t2 *__
   s.y = s.y + bc > 0 ? s.y : -bc;
   x[v] = s;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Semi-implicit steps ON THE FUSED TILES (fem_plan_run_imex_fused): the two diffusion solves by Chebyshev iteration.
+// Conjugate gradients need two global dot products per iteration, i.e. launch-wide synchronisation twice per matrix
+// product; the Chebyshev iteration needs none -- its coefficients come from bounds on the spectrum, known here a
+// priori: A = I - dt D_f L, L = M^-1 K with real eigenvalues in [-2 max_v sum_j w_vj, 0] (Gershgorin; self-adjoint in
+// the M inner product), so A's lie in [1, 1 + 2 dt D_f max_v sum_j w_vj].  An iteration is then exactly what an
+// explicit step is to the tile machinery: every row needs its neighbours' current iterate and nothing else, so k
+// iterations run per launch on a tile with k rings, the iterate in LDS, the weights in registers:
+//     r_s = b - A x_s ;  d_s = c1_s d_(s-1) + c2_s r_s ;  x_(s+1) = x_s + d_s          (Saad, Iterative Methods, Alg. 12.1)
+// with c1_0 = 0, c2_0 = 1 / theta, then c1_s = rho_s rho_(s-1), c2_s = 2 rho_s / delta, rho_0 = delta / theta,
+// rho_s = 1 / (2 theta / delta - rho_(s-1)), theta / delta = centre / half-width of the interval; one sequence per
+// field (D_n = D, D_c = 1).  Per row the kernel keeps b and d in registers; ring rows reload the owner's d each launch.
+// The operator stream is the Laplacian weights alone (4 or 8 B per entry, extracted once: tile_weights_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T> struct ChebArgs { T c1n[8], c2n[8], c1c[8], c2c[8], dtDn, dtDc; int first; };
+
+// weights of the register rows out of a plan's tile blocks: fmt 0 four scalars, 1 twelve-byte records (fp32), 2 mixed records (fp64)
+template <typename T>
+__global__ __launch_bounds__(256) void tile_weights_kernel(const void *__restrict__ coef, T *__restrict__ tw, const uint *__restrict__ meta,
+                                                           uint W, int fmt) {
+  const uint *mt = meta + 16 * (size_t)blockIdx.x;
+  const size_t roff = mt[2], n = (size_t)W * mt[3];
+  for (size_t le = threadIdx.x; le < n; le += 256) {
+    T w;
+    if (fmt == 1) w = (T) reinterpret_cast<const float *>(coef)[4 * roff + 3 * le];
+    else if (fmt == 2) w = (T) reinterpret_cast<const double *>(coef)[4 * roff + le];
+    else w = reinterpret_cast<const T *>(coef)[4 * (roff + le)];
+    tw[roff + le] = w;
+  }
+}
+
+template <typename T, int TPB, int R, int W, int MINW>
+__global__ __launch_bounds__(TPB, MINW) void tile_cheb_kernel(
+    const typename Vec<T>::t2 *__restrict__ xin, typename Vec<T>::t2 *__restrict__ xout, const typename Vec<T>::t2 *__restrict__ rhs,
+    const typename Vec<T>::t2 *__restrict__ din, typename Vec<T>::t2 *__restrict__ dout, const uint *__restrict__ meta,
+    const uint *__restrict__ ghost, const uint *__restrict__ idx2, const T *__restrict__ tw, uint ntiles, uint maxLocal, int nit,
+    ChebArgs<T> a) {
+  typedef typename Vec<T>::t2 T2;
+  extern __shared__ __align__(16) unsigned char tile_smem[];
+  const uint bid = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, xcd = bid & 7u;
+  const uint tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const uint *mt = meta + 16 * (size_t)tile;
+  const uint base = mt[0], goff = mt[1], roff = mt[2], rpad = mt[3], k = mt[4];
+  const uint n0 = mt[5], mk = mt[5 + k], rows = mt[5 + k - 1];
+  T2 *cur = reinterpret_cast<T2 *>(tile_smem);
+  T2 *nxt = cur + maxLocal;
+  const uint t = threadIdx.x;
+  const T *__restrict__ twt = tw + roff;
+  const uint *__restrict__ tidx = idx2 + (roff >> 1);
+  // all loads unconditional with clamped indices, in flight together: ids of the rows this thread steps, weights and
+  // packed column offsets of its register rows, b and d of those rows, then the iterate of every local row
+  uint gid[R];
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    const uint r = min(t + TPB * q, rows - 1);
+    gid[q] = r < n0 ? base + r : ghost[goff + (r - n0)];
+  }
+  T w[R][W];
+  uint ix[R][W / 2];
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    const uint r = min(t + TPB * q, rpad - 1);
+#pragma unroll
+    for (int e = 0; e < W; e++) w[q][e] = __builtin_nontemporal_load(&twt[e * rpad + r]);
+#pragma unroll
+    for (int e = 0; e < W / 2; e++) ix[q][e] = __builtin_nontemporal_load(&tidx[e * rpad + r]) * (uint)sizeof(T2);
+  }
+  T2 bb[R], dd[R];
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    bb[q] = rhs[gid[q]];
+    dd[q] = din[gid[q]];                    // (the first launch of a solve reads whatever the buffer holds and ignores it)
+    if (a.first) { dd[q].x = 0; dd[q].y = 0; }
+  }
+  for (uint i = t; i < mk; i += TPB) cur[i] = xin[i < n0 ? base + i : ghost[goff + (i - n0)]];
+  __syncthreads();
+  for (int s = 0; s < nit; s++) {
+    const uint lim = mt[5 + k - 1 - s];
+    const T c1n = a.c1n[s], c2n = a.c2n[s], c1c = a.c1c[s], c2c = a.c2c[s];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      const uint r = t + TPB * q;
+      if (r < lim) {
+        const T2 self = cur[r];
+        T ln = 0, lc = 0;
+#pragma unroll
+        for (int e = 0; e < W; e++) {
+          const uint joff = (e & 1) ? (ix[q][e >> 1] >> 16) : (ix[q][e >> 1] & 0xffffu);
+          const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
+          ln += w[q][e] * (f.x - self.x); lc += w[q][e] * (f.y - self.y);
+        }
+        const T rn = bb[q].x - (self.x - a.dtDn * ln), rc = bb[q].y - (self.y - a.dtDc * lc);
+        dd[q].x = c1n * dd[q].x + c2n * rn; dd[q].y = c1c * dd[q].y + c2c * rc;
+        T2 o;
+        o.x = self.x + dd[q].x; o.y = self.y + dd[q].y;
+        nxt[r] = o;
+      }
+    }
+    __syncthreads();
+    T2 *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  for (uint i = t; i < n0; i += TPB) xout[base + i] = cur[i];
+#pragma unroll
+  for (int q = 0; q < R; q++)
+    if (t + TPB * q < n0) dout[base + t + TPB * q] = dd[q];
+}

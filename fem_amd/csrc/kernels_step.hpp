@@ -250,7 +250,9 @@ template <bool COH, typename T2> __device__ __forceinline__ void state_store(T2 
   }
 }
 
-template <typename T, int TPB, int R, int W, int X, int PRO, int PK, int COH>
+// MODE 1 (tile_rhs_kernel, semi-implicit stepping on fused tiles): the step's update is the explicit right-hand side
+// b = u + dt (reaction + chemotaxis terms) without the diffusion terms and without the clamp (imex_rhs_update).
+template <typename T, int TPB, int R, int W, int X, int PRO, int PK, int COH, int MODE = 0>
 __device__ __forceinline__ void tile_body(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
@@ -498,7 +500,8 @@ __device__ __forceinline__ void tile_body(
             gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
           }
         }
-        nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+        if constexpr (MODE == 1) nxt[r] = imex_rhs_update<T>(self, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+        else nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
       }
       if constexpr (kTileRowFence) __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
     }
@@ -517,6 +520,18 @@ __global__ __launch_bounds__(TPB, MINW) void tile_step_kernel(
   const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
   const uint tile = tile0 + (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);   // tiles [tile0, tile0 + ntiles)
   tile_body<T, TPB, R, W, X, PRO, PK, 0>(src, dst, meta, ghost, idx2, coef, xinfo, tile, maxLocal, maxExtra, nsteps, m);
+}
+
+// one "step" of every tile with the explicit right-hand side of a semi-implicit step as its update (kernels_implicit.hpp)
+template <typename T, int TPB, int R, int W, int MINW, int X, int PK>
+__global__ __launch_bounds__(TPB, MINW) void tile_rhs_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
+    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint ntiles,
+    uint maxLocal, uint maxExtra, ModelT<T> m) {
+  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
+  const uint tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);
+  tile_body<T, TPB, R, W, X, 1, PK, 0, 1>(src, dst, meta, ghost, idx2, coef, xinfo, tile, maxLocal, maxExtra, 1, m);
 }
 
 // ---------------------------------------------------------------------------

@@ -367,6 +367,15 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
  * device, no host synchronisation.  Plan must carry FEM_PLAN_IMPLICIT.  fem_plan_imex_residual:
  * preconditioned residual norm of the last solve relative to its first one (synchronises). */
 int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
+/* The same semi-implicit steps on a FUSED-TILE plan (fem_plan_create_tiled, whole mesh, rows of at most 6 entries; no
+ * flag needed), the two diffusion solves by Chebyshev iteration instead of conjugate gradients: its coefficients come
+ * from a priori bounds on the spectrum (1 <= lambda <= 1 + 2 dt D max_v sum_j w_vj), so an iteration needs no dot
+ * product -- it is to the tile kernel what an explicit step is, and ksteps iterations run per launch with the iterate in
+ * LDS and the Laplacian weights in registers.  The iteration count follows from the bounds and rel_tol (the Chebyshev
+ * error bound, in the energy norm relative to the first iterate's error; fem_plan_imex_fused_iterations returns it).
+ * No counterpart in the reference (as fem_plan_run_imex).  4.1M vertices, dt = 30 x the explicit step: see DESIGN.md. */
+int fem_plan_run_imex_fused(fem_plan *p, int nsteps, double dt, const fem_model *model, double rel_tol, void *stream);
+int fem_plan_imex_fused_iterations(const fem_plan *p);
 int fem_plan_imex_residual(fem_plan *p, double *rel_n, double *rel_c);
 /* Residual-based stop (default 0 = every solve takes exactly cg_iterations): with rel_tol > 0 a solve ends as soon as
  * the preconditioned residual of BOTH fields is <= rel_tol times its first one; cg_iterations is then the upper bound.

@@ -105,3 +105,51 @@ def test_imex_requires_flag_and_layout():
         fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=2, implicit=True)
     with pytest.raises(fa.FemError):
         fa.Plan(case.mesh, fa.PREC_F64, implicit=True).imex_residual()
+
+
+@pytest.mark.parametrize("make,nparts,factor,ksteps", [(lambda n: sphere_case(16, n), 6, 1.0, 4), (lambda n: sphere_case(16, n), 6, 8.0, 4),
+                                                       (lambda n: sphere_case(24, n), 8, 30.0, 7), (lambda n: strip_case(n), 3, 4.0, 3)])
+def test_imex_on_fused_tiles_matches_scipy(make, nparts, factor, ksteps):
+    """fem_plan_run_imex_fused: the same semi-implicit step on a fused-tile plan, the diffusion solves by Chebyshev
+    iteration (ksteps iterations per launch, no dot products) -- against the scipy direct solves, in fp64 (tolerance
+    1e-12: as close as the CG path), in the reference's precision mix and in fp32 with 12-byte records (1e-6); the
+    iteration count is the a-priori one and grows with the time step"""
+    case = make(nparts)
+    case.mesh.init_stats(fa.PREC_F64)
+    st = case.ostats(ol.F64)
+    dt = factor * stable_dt(st, case.model, safety=1.0)
+    n0, c0 = smooth_ic(case.pts)
+    model = case.model.as_array()
+    n_ref, c_ref = scipy_imex(st, case.topo, n0, c0, dt, 5, model)
+    plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+    plan.set_state(n0, c0)
+    plan.run_imex_fused(5, dt, case.model, rel_tol=1e-12)
+    n, c = plan.get_state()
+    its = plan.imex_fused_iterations()
+    e = parity(n, c, n_ref, c_ref, 1e-9)
+    assert 5 <= its <= 400, its
+    plan.run_imex_fused(1, 2 * dt, case.model, rel_tol=1e-12)
+    assert plan.imex_fused_iterations() > its
+    mixed = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps, mixed=True)
+    mixed.set_state(n0, c0)
+    mixed.run_imex_fused(5, dt, case.model, rel_tol=1e-12)
+    parity(*mixed.get_state(), n_ref, c_ref, 1e-8, tol_dev=1e-5)
+    plan32 = fa.Plan(case.mesh, fa.PREC_F32, part=case.part, ksteps=ksteps)
+    plan32.set_state(n0, c0)
+    plan32.run_imex_fused(5, dt, case.model, rel_tol=1e-6)
+    n32, c32 = plan32.get_state()
+    e32 = parity(n32, c32, n_ref, c_ref, 1e-5, tol_dev=1e-3)
+    print("fused imex: %d iterations; f64 %s; f32 %s" % (its, e, e32))
+
+
+def test_imex_on_fused_tiles_refuses_what_it_does_not_cover():
+    case = scan_case(16, 5)
+    case.mesh.init_stats(fa.PREC_F64)
+    with pytest.raises(fa.FemError, match="6 entries"):
+        fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=3).run_imex_fused(1, 1e-3)
+    sp_ = sphere_case(6, 2)
+    sp_.mesh.init_stats(fa.PREC_F64)
+    with pytest.raises(fa.FemError, match="fused-tile"):
+        fa.Plan(sp_.mesh, fa.PREC_F64).run_imex_fused(1, 1e-3)
+    with pytest.raises(fa.FemError):
+        fa.Plan(sp_.mesh, fa.PREC_F64, part=sp_.part, ksteps=2).run_imex_fused(1, 1e-3, rel_tol=0.0)
