@@ -455,10 +455,11 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
       return p->mixed ? (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 2> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 2>)
                       : (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 0> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 0>);
   }();
-  auto chebKern = tile_cheb_kernel<T, TPB, R, kTileW, MINW>;
+  auto chebKern = p->maxExtra ? tile_cheb_kernel<T, TPB, R, kTileW, MINW, true> : tile_cheb_kernel<T, TPB, R, kTileW, MINW, false>;
+  const fem_uint maxExtraEven = (p->maxExtra + 1) & ~1u;         // keeps the LDS arrays behind the iterate buffers aligned
   const size_t ldsRhs = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
                         (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
-  const size_t ldsCheb = 2 * (size_t)p->maxLocal * sizeof(T2);
+  const size_t ldsCheb = 2 * (size_t)p->maxLocal * sizeof(T2) + (p->maxExtra ? (size_t)maxExtraEven * (sizeof(T) + 4) + (size_t)TPB * R * 4 : 0);
   if (ldsRhs > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rhsKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRhs));
   if (ldsCheb > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)chebKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsCheb));
   for (int s = 0; s < nsteps; s++) {
@@ -489,7 +490,8 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
         }
       }
       hipLaunchKernelGGL(chebKern, dim3(p->ntiles), dim3(TPB), ldsCheb, st, xin, xout, (const T2 *)p->cb_b, (const T2 *)p->cb_d[l & 1],
-                         (T2 *)p->cb_d[(l & 1) ^ 1], p->tmeta.p, p->tghost.p, p->tidx2.p, (const T *)p->cb_tw, p->ntiles, p->maxLocal, nit, a);
+                         (T2 *)p->cb_d[(l & 1) ^ 1], p->tmeta.p, p->tghost.p, p->tidx2.p, (const T *)p->cb_tw, p->txinfo.p, p->ntiles,
+                         p->maxLocal, maxExtraEven, nit, a);
       xin = xout;
     }
     hipLaunchKernelGGL(imex_clamp_kernel<T>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, out, p->V, (T)p->base_n, (T)p->base_c);
@@ -1258,7 +1260,6 @@ int fem_plan_run_imex_fused(fem_plan *p, int nsteps, double dt, const fem_model 
   if (!p || nsteps < 0 || !(dt > 0) || !(rel_tol > 0) || rel_tol >= 1) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: bad argument (0 < rel_tol < 1)");
   if (p->ksteps < 1 || (p->tcfg != kDefaultTileCfg && p->tcfg != kDefaultTileCfgWide) || p->can_assemble)
     return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: needs a fused-tile plan (fem_plan_create_tiled) on a default register tile, operator from the host assembly");
-  if (p->maxExtra) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: rows of more than 6 entries are not supported (use fem_plan_run_imex)");
   if (p->nGhost || p->nBoundary) return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused: whole-mesh plans only");
   fem_model dm;
   if (!model) { fem_default_model(&dm); model = &dm; }

@@ -222,7 +222,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void tile_weights_kernel(const void *__restrict__ coef, T *__restrict__ tw, const uint *__restrict__ meta,
                                                            uint W, int fmt) {
   const uint *mt = meta + 16 * (size_t)blockIdx.x;
-  const size_t roff = mt[2], n = (size_t)W * mt[3];
+  const size_t roff = mt[2], n = (size_t)W * mt[3], nx = mt[15];
   for (size_t le = threadIdx.x; le < n; le += 256) {
     T w;
     if (fmt == 1) w = (T) reinterpret_cast<const float *>(coef)[4 * roff + 3 * le];
@@ -230,14 +230,18 @@ __global__ __launch_bounds__(256) void tile_weights_kernel(const void *__restric
     else w = reinterpret_cast<const T *>(coef)[4 * (roff + le)];
     tw[roff + le] = w;
   }
+  // the entries beyond W of wide rows: four scalars of the plan's type behind the block in every format
+  for (size_t e = threadIdx.x; e < nx; e += 256) tw[roff + n + e] = reinterpret_cast<const T *>(coef)[4 * (roff + n + e)];
 }
 
-template <typename T, int TPB, int R, int W, int MINW>
+// X: the plan has rows of more than W entries (irregular meshes); their further entries ("extras") are staged in LDS
+// as in tile_body -- weight, column offset, and per row (first extra | count << 16).
+template <typename T, int TPB, int R, int W, int MINW, bool X = false>
 __global__ __launch_bounds__(TPB, MINW) void tile_cheb_kernel(
     const typename Vec<T>::t2 *__restrict__ xin, typename Vec<T>::t2 *__restrict__ xout, const typename Vec<T>::t2 *__restrict__ rhs,
     const typename Vec<T>::t2 *__restrict__ din, typename Vec<T>::t2 *__restrict__ dout, const uint *__restrict__ meta,
-    const uint *__restrict__ ghost, const uint *__restrict__ idx2, const T *__restrict__ tw, uint ntiles, uint maxLocal, int nit,
-    ChebArgs<T> a) {
+    const uint *__restrict__ ghost, const uint *__restrict__ idx2, const T *__restrict__ tw, const uint *__restrict__ xinfo,
+    uint ntiles, uint maxLocal, uint maxExtra, int nit, ChebArgs<T> a) {
   typedef typename Vec<T>::t2 T2;
   extern __shared__ __align__(16) unsigned char tile_smem[];
   const uint bid = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, xcd = bid & 7u;
@@ -247,6 +251,10 @@ __global__ __launch_bounds__(TPB, MINW) void tile_cheb_kernel(
   const uint n0 = mt[5], mk = mt[5 + k], rows = mt[5 + k - 1];
   T2 *cur = reinterpret_cast<T2 *>(tile_smem);
   T2 *nxt = cur + maxLocal;
+  T *xs_w = reinterpret_cast<T *>(nxt + maxLocal);               // X: [maxExtra] weights (maxExtra rounded up to even: aligned)
+  uint *xs_off = reinterpret_cast<uint *>(xs_w + maxExtra);      //    [maxExtra] byte offsets of their columns
+  uint *xs_info = xs_off + maxExtra;                             //    [TPB * R]  first extra | count << 16 per row
+  const uint xoff = mt[14], xcnt = X ? mt[15] : 0u;
   const uint t = threadIdx.x;
   const T *__restrict__ twt = tw + roff;
   const uint *__restrict__ tidx = idx2 + (roff >> 1);
@@ -275,6 +283,13 @@ __global__ __launch_bounds__(TPB, MINW) void tile_cheb_kernel(
     dd[q] = din[gid[q]];                    // (the first launch of a solve reads whatever the buffer holds and ignores it)
     if (a.first) { dd[q].x = 0; dd[q].y = 0; }
   }
+  if (X && xcnt) {                                                // tile-uniform
+    for (uint i = t; i < rpad; i += TPB) xs_info[i] = xinfo[xoff + i];
+    for (uint i = t; i < xcnt; i += TPB) {
+      xs_w[i] = twt[W * rpad + i];
+      xs_off[i] = xinfo[xoff + rpad + i] * (uint)sizeof(T2);
+    }
+  }
   for (uint i = t; i < mk; i += TPB) cur[i] = xin[i < n0 ? base + i : ghost[goff + (i - n0)]];
   __syncthreads();
   for (int s = 0; s < nit; s++) {
@@ -291,6 +306,13 @@ __global__ __launch_bounds__(TPB, MINW) void tile_cheb_kernel(
           const uint joff = (e & 1) ? (ix[q][e >> 1] >> 16) : (ix[q][e >> 1] & 0xffffu);
           const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
           ln += w[q][e] * (f.x - self.x); lc += w[q][e] * (f.y - self.y);
+        }
+        if (X && xcnt) {                                         // entries W, W+1, ... of a wide row
+          const uint xi = xs_info[r];
+          for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {
+            const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
+            ln += xs_w[e] * (f.x - self.x); lc += xs_w[e] * (f.y - self.y);
+          }
         }
         const T rn = bb[q].x - (self.x - a.dtDn * ln), rc = bb[q].y - (self.y - a.dtDc * lc);
         dd[q].x = c1n * dd[q].x + c2n * rn; dd[q].y = c1c * dd[q].y + c2c * rc;

@@ -367,8 +367,7 @@ int fem_plan_run(fem_plan *p, int nsteps, double dt, const fem_model *model, voi
  * device, no host synchronisation.  Plan must carry FEM_PLAN_IMPLICIT.  fem_plan_imex_residual:
  * preconditioned residual norm of the last solve relative to its first one (synchronises). */
 int fem_plan_run_imex(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
-/* The same semi-implicit steps on a FUSED-TILE plan (fem_plan_create_tiled, whole mesh, rows of at most 6 entries; no
- * flag needed), the two diffusion solves by Chebyshev iteration instead of conjugate gradients: its coefficients come
+/* The same semi-implicit steps on a FUSED-TILE plan (fem_plan_create_tiled, whole mesh; no flag needed), the two diffusion solves by Chebyshev iteration instead of conjugate gradients: its coefficients come
  * from a priori bounds on the spectrum (1 <= lambda <= 1 + 2 dt D max_v sum_j w_vj), so an iteration needs no dot
  * product -- it is to the tile kernel what an explicit step is, and ksteps iterations run per launch with the iterate in
  * LDS and the Laplacian weights in registers.  The iteration count follows from the bounds and rel_tol (the Chebyshev

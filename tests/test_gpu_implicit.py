@@ -108,12 +108,14 @@ def test_imex_requires_flag_and_layout():
 
 
 @pytest.mark.parametrize("make,nparts,factor,ksteps", [(lambda n: sphere_case(16, n), 6, 1.0, 4), (lambda n: sphere_case(16, n), 6, 8.0, 4),
-                                                       (lambda n: sphere_case(24, n), 8, 30.0, 7), (lambda n: strip_case(n), 3, 4.0, 3)])
+                                                       (lambda n: sphere_case(24, n), 8, 30.0, 7), (lambda n: strip_case(n), 3, 4.0, 3),
+                                                       (lambda n: scan_case(16, n), 5, 6.0, 4)])
 def test_imex_on_fused_tiles_matches_scipy(make, nparts, factor, ksteps):
     """fem_plan_run_imex_fused: the same semi-implicit step on a fused-tile plan, the diffusion solves by Chebyshev
     iteration (ksteps iterations per launch, no dot products) -- against the scipy direct solves, in fp64 (tolerance
     1e-12: as close as the CG path), in the reference's precision mix and in fp32 with 12-byte records (1e-6); the
-    iteration count is the a-priori one and grows with the time step"""
+    iteration count is the a-priori one and grows with the time step; the irregular mesh exercises the rows of more than
+    6 entries (extras staged in LDS)"""
     case = make(nparts)
     case.mesh.init_stats(fa.PREC_F64)
     st = case.ostats(ol.F64)
@@ -143,10 +145,6 @@ def test_imex_on_fused_tiles_matches_scipy(make, nparts, factor, ksteps):
 
 
 def test_imex_on_fused_tiles_refuses_what_it_does_not_cover():
-    case = scan_case(16, 5)
-    case.mesh.init_stats(fa.PREC_F64)
-    with pytest.raises(fa.FemError, match="6 entries"):
-        fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=3).run_imex_fused(1, 1e-3)
     sp_ = sphere_case(6, 2)
     sp_.mesh.init_stats(fa.PREC_F64)
     with pytest.raises(fa.FemError, match="fused-tile"):
