@@ -410,8 +410,16 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
 
 // Semi-implicit steps on a fused-tile plan (kernels_implicit.hpp, second half): right-hand side by one pass of the tile
 // kernel, then ceil(N / k) launches of k Chebyshev iterations each, N from the spectrum bounds and the tolerance.
+// comm != null: the plan is a shard's.  Every launch runs ALL local tiles (the ghost rows are iterated locally, a ring less
+// valid per iteration), and the ghost rows of a vector are fetched from their owners through comm->exchange: the
+// right-hand side once, the iterate and the direction after every launch of k iterations, the new state at the end -- 2 L
+// exchanges per step for L launches, and no all-reduce: the spectrum bound `wsum` is the same number on every rank (the
+// caller passes the whole mesh's), so all ranks run the same coefficient sequence.
 template <typename T, int C>
-static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *model, double tol, hipStream_t st) {
+static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *model, double tol, hipStream_t st,
+                        const fem_imex_comm *comm = nullptr, double wsum = 0) {
+  auto ghosts = [&](void *vec) -> int { return comm ? comm->exchange(comm->ctx, (uint64_t)vec, (void *)st) : FEM_OK; };
+  if (!(wsum > 0)) wsum = p->wsum_max;
   typedef typename Vec<T>::t2 T2;
   typedef typename Vec<T>::t4 T4;
   constexpr int TPB = kTileCfgs[C].tpb, R = kTileCfgs[C].r;
@@ -437,7 +445,7 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
   double theta[2], delta[2];
   int N = 1;
   for (int f = 0; f < 2; f++) {
-    const double hi = 1.0 + 2.0 * dt * Df[f] * p->wsum_max * 1.001;
+    const double hi = 1.0 + 2.0 * dt * Df[f] * wsum * 1.001;
     theta[f] = 0.5 * (hi + 1.0); delta[f] = 0.5 * (hi - 1.0);
     const double kappa = hi, rho = (std::sqrt(kappa) - 1.0) / (std::sqrt(kappa) + 1.0);
     if (rho > 0) N = std::max(N, (int)std::ceil(std::log(2.0 / tol) / -std::log(rho)));
@@ -467,6 +475,7 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
     T2 *out = (T2 *)p->state[p->cur ^ 1];
     hipLaunchKernelGGL(rhsKern, dim3(p->ntiles), dim3(TPB), ldsRhs, st, u, (T2 *)p->cb_b, p->tmeta.p, p->tghost.p, p->tidx2.p,
                        (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra, m);
+    { const int rc = ghosts(p->cb_b); if (rc != FEM_OK) return rc; }
     // x_0 = b; the iterate alternates between two buffers so that the last launch writes the plan's next state
     double rho[2] = {delta[0] / theta[0], delta[1] / theta[1]};
     const T2 *xin = (const T2 *)p->cb_b;
@@ -493,8 +502,14 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
                          (T2 *)p->cb_d[(l & 1) ^ 1], p->tmeta.p, p->tghost.p, p->tidx2.p, (const T *)p->cb_tw, p->txinfo.p, p->ntiles,
                          p->maxLocal, maxExtraEven, nit, a);
       xin = xout;
+      if (comm && l + 1 < launches) {
+        int rc = ghosts(xout);
+        if (rc == FEM_OK) rc = ghosts(p->cb_d[(l & 1) ^ 1]);
+        if (rc != FEM_OK) return rc;
+      }
     }
     hipLaunchKernelGGL(imex_clamp_kernel<T>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, out, p->V, (T)p->base_n, (T)p->base_c);
+    { const int rc = ghosts(out); if (rc != FEM_OK) return rc; }
     p->cur ^= 1;
   }
   HIP_TRY(hipGetLastError());
@@ -1269,6 +1284,24 @@ int fem_plan_run_imex_fused(fem_plan *p, int nsteps, double dt, const fem_model 
                                       : runImexFused<float, kDefaultTileCfgWide>(p, nsteps, dt, model, rel_tol, st);
   return p->tcfg == kDefaultTileCfg ? runImexFused<double, kDefaultTileCfg>(p, nsteps, dt, model, rel_tol, st)
                                     : runImexFused<double, kDefaultTileCfgWide>(p, nsteps, dt, model, rel_tol, st);
+  });
+}
+
+int fem_plan_run_imex_fused_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, double rel_tol, double wsum_max,
+                                    const fem_imex_comm *comm, void *stream) {
+  return fem::guarded("fem_plan_run_imex_fused_sharded", [&]() -> int {
+  if (!p || nsteps < 0 || !(dt > 0) || !(rel_tol > 0) || rel_tol >= 1 || !comm || !comm->exchange || !(wsum_max > 0))
+    return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused_sharded: bad argument (0 < rel_tol < 1, wsum_max > 0, an exchange callback)");
+  if (p->ksteps < 1 || (p->tcfg != kDefaultTileCfg && p->tcfg != kDefaultTileCfgWide) || p->can_assemble)
+    return fail(FEM_ERR_INVALID, "fem_plan_run_imex_fused_sharded: needs a shard's fused-tile plan on a default register tile, operator from the host assembly");
+  fem_model dm;
+  if (!model) { fem_default_model(&dm); model = &dm; }
+  hipStream_t st = (hipStream_t)stream;
+  if (p->precision == FEM_PREC_F32)
+    return p->tcfg == kDefaultTileCfg ? runImexFused<float, kDefaultTileCfg>(p, nsteps, dt, model, rel_tol, st, comm, wsum_max)
+                                      : runImexFused<float, kDefaultTileCfgWide>(p, nsteps, dt, model, rel_tol, st, comm, wsum_max);
+  return p->tcfg == kDefaultTileCfg ? runImexFused<double, kDefaultTileCfg>(p, nsteps, dt, model, rel_tol, st, comm, wsum_max)
+                                    : runImexFused<double, kDefaultTileCfgWide>(p, nsteps, dt, model, rel_tol, st, comm, wsum_max);
   });
 }
 

@@ -329,6 +329,16 @@ int fem_dist_run_imex(fem_dist *d, int nsteps, double dt, const fem_model *model
   return rc;
 }
 
+int fem_dist_run_imex_fused(fem_dist *d, int nsteps, double dt, const fem_model *model, double rel_tol, double wsum_max, void *stream) {
+  if (!d) return fail(FEM_ERR_INVALID, "fem_dist_run_imex_fused: null");
+  g_detail.clear();
+  fem_imex_comm comm = {d, imexExchange, imexAllreduce};       // the Chebyshev solver calls the exchange only
+  const int rc = fem_plan_run_imex_fused_sharded(d->plan, nsteps, dt, model, rel_tol, wsum_max, &comm, stream);
+  if (rc != FEM_OK && g_detail.empty()) g_detail = fem_error_detail();
+  if (rc != FEM_OK && d->world) d->world->barrier.abort();
+  return rc;
+}
+
 int fem_dist_device_count(void) {
   int n = 0;
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;

@@ -40,6 +40,7 @@ struct Options {
   // halo exchange over RCCL (or device-to-device copies inside this process: --transport inproc)
   int ranks = 0, krings = 0, precision = FEM_PREC_F32;
   int imex = 0;                      // --imex ITERS: semi-implicit steps, ITERS CG iterations each (sharded mode)
+  double imexFused = 0;              // --imex-fused TOL: semi-implicit steps on the shards' fused tiles, Chebyshev iteration to TOL (sharded mode)
   double dtScale = 1.0;              // --dt-scale: time step = scale x 0.1 maxEdgeLen^2
   double watchdog = -1;              // --watchdog SECONDS (sharded runs; default 600, 0 = off): a run that has not finished by then reports where every rank is and exits 124
   bool inproc = false;
@@ -273,7 +274,13 @@ class ThreadBarrier {
 double shardedRun(int n, const Options &o, const fem_model &model, const Run &r) {
   const int R = o.ranks;
   if (n < R) { std::fprintf(stderr, "--ranks %d needs at least that many partitions (have %d)\n", R, n); return -1; }
-  const int krings = o.krings > 0 ? o.krings : (o.imex > 0 ? 1 : std::max(2, 2 * o.fuse));
+  const int krings = o.krings > 0 ? o.krings : (o.imex > 0 ? 1 : (o.imexFused > 0 ? std::max(1, o.fuse) : std::max(2, 2 * o.fuse)));
+  double wsumMax = 0;                // spectrum bound of the Chebyshev solver: the whole mesh's largest |wVtx| (the same on every rank)
+  if (o.imexFused > 0) {
+    const double *wVtx = nullptr;
+    if (!ok(fem_mesh_stats(r.ordered, nullptr, nullptr, nullptr, nullptr, nullptr, &wVtx, nullptr, nullptr, nullptr), "stats") || !wVtx) return -1;
+    for (int i = 0; i < r.V; i++) wsumMax = std::max(wsumMax, std::fabs(wVtx[i]));
+  }
   const int ndev = std::max(1, fem_dist_device_count());
   if (!o.inproc && R > ndev) {     // RCCL refuses (or hangs on) two ranks of one communicator on the same GPU
     std::fprintf(stderr, "--ranks %d over RCCL needs that many GPUs (this host shows %d); --transport inproc lets ranks share one\n", R, ndev);
@@ -291,7 +298,7 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
   std::vector<fem_uint> ghosts(R, 0);
   int errorsRound2 = 0;
   std::vector<double> hn, hc;
-  const bool check = r.V <= 4000000 && o.imex == 0;   // CPUrun (explicit steps) of a large mesh takes minutes: check up to 4M vertices
+  const bool check = r.V <= 4000000 && o.imex == 0 && !(o.imexFused > 0);   // CPUrun (explicit steps) of a large mesh takes minutes: check up to 4M vertices
   if (check && !hostRun(r, model, 2, hn, hc)) return -1;
 
   // where every rank is, for the watchdog: a run that hangs (a rank waiting for the GPU or for another rank) ends with
@@ -373,7 +380,8 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
     if (up) {
       // two warm-up steps and the check against CPUrun (main.cpp:480-541)
       stage[rank] = "two warm-up steps (issuing)";
-      if ((o.imex > 0 ? fem_dist_run_imex(dist, 2, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2, r.dt, &model, stream)) != FEM_OK) { bail("step", true); }
+      if ((o.imexFused > 0 ? fem_dist_run_imex_fused(dist, 2, r.dt, &model, o.imexFused, wsumMax, stream)
+                           : (o.imex > 0 ? fem_dist_run_imex(dist, 2, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2, r.dt, &model, stream))) != FEM_OK) { bail("step", true); }
       else download();
     }
     stage[rank] = "warm-up done, waiting for the other ranks";
@@ -383,7 +391,8 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
     if (up && !failed && !o.debug) {
       const double t0 = seconds();
       stage[rank] = "timed steps (issuing)";
-      if ((o.imex > 0 ? fem_dist_run_imex(dist, 2 * o.maxIt, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2 * o.maxIt, r.dt, &model, stream)) != FEM_OK ||
+      if ((o.imexFused > 0 ? fem_dist_run_imex_fused(dist, 2 * o.maxIt, r.dt, &model, o.imexFused, wsumMax, stream)
+                           : (o.imex > 0 ? fem_dist_run_imex(dist, 2 * o.maxIt, r.dt, &model, o.imex, stream) : fem_dist_run(dist, 2 * o.maxIt, r.dt, &model, stream))) != FEM_OK ||
           fem_dist_wait(dist, stream) != FEM_OK ||
           (stage[rank] = "timed steps (stream synchronize)", fem_dist_stream_synchronize(stream)) != FEM_OK)
         bail("step", true);
@@ -451,6 +460,8 @@ int usage() {
                "                   --mixed: fp64 plans in the reference's own precision mix (fp32 gradient branch; fused runs);\n"
                "                   (--f64 and --mixed also without --ranks: the native single-GPU plan in that precision)\n"
                "                   --dump FILE: final state as raw doubles n[V], c[V] (ordered numbering);\n"
+               "                   --imex-fused TOL: semi-implicit steps on the fused tiles (Chebyshev iteration to relative tolerance\n"
+               "                   TOL, --fuse K iterations per launch and between halo exchanges; no all-reduce);\n"
                "                   --imex ITERS: semi-implicit steps (diffusion by ITERS CG iterations, dot products all-reduced\n"
                "                   over the ranks), --dt-scale S: time step = S x 0.1 maxEdgeLen^2;\n"
                "                   --watchdog SECONDS (default 600, 0 = off): if the run has not finished by then, say where every rank\n"
@@ -474,7 +485,7 @@ int main(int argc, char **argv) {
     else if (a == "--f64") { o.precision = FEM_PREC_F64; o.native = true; }
     else if (a == "--mixed") { o.precision = FEM_PREC_F64; o.mixed = true; o.native = true; }
     else if (a == "-n" || a == "--iterations" || a == "--seed" || a == "--fuse" || a == "--rows" || a == "--out" ||
-             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--dt-scale" || a == "--watchdog") {
+             a == "--ranks" || a == "--rings" || a == "--transport" || a == "--dump" || a == "--imex" || a == "--imex-fused" || a == "--dt-scale" || a == "--watchdog") {
       const char *v = value();
       if (!v) return usage();
       if (a == "-n") {
@@ -490,6 +501,7 @@ int main(int argc, char **argv) {
       else if (a == "--transport") { if (!std::strcmp(v, "inproc")) o.inproc = true; else if (std::strcmp(v, "rccl")) return usage(); }
       else if (a == "--dump") o.dump = v;
       else if (a == "--imex") o.imex = std::atoi(v);
+      else if (a == "--imex-fused") o.imexFused = std::atof(v);
       else if (a == "--dt-scale") o.dtScale = std::atof(v);
       else if (a == "--watchdog") o.watchdog = std::atof(v);
       else o.out = v;
@@ -499,6 +511,7 @@ int main(int argc, char **argv) {
   }
   if (o.file.empty() || o.startN < 1 || o.endN < o.startN || o.maxIt < 1 || o.fuse < 0 || o.fuse > 8 || o.rowsPerPart < 1 ||
       (o.hostConstants && !o.native) || (o.mixed && (!o.native || o.fuse < 1 || o.imex > 0)) || (o.precision == FEM_PREC_F64 && !o.native) || o.ranks < 0 || o.ranks > 64 || o.krings < 0 || o.imex < 0 || (o.imex > 0 && o.ranks < 1) ||
+      o.imexFused < 0 || o.imexFused >= 1 || (o.imexFused > 0 && (o.ranks < 1 || o.fuse < 1 || o.imex > 0)) ||
       !(o.dtScale > 0))
     return usage();
 

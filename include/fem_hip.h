@@ -399,6 +399,13 @@ typedef struct {
 } fem_imex_comm;
 int fem_plan_run_imex_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, fem_uint n_own,
                               const fem_imex_comm *comm, void *stream);
+/* fem_plan_run_imex_fused on a shard's fused-tile plan (fem_plan_create_tiled with the shard; ksteps <= its ghost rings).
+ * Only comm->exchange is used: the right-hand side once, iterate and direction after every launch of ksteps
+ * iterations, the new state at the end -- no all-reduce, because the Chebyshev coefficients come from wsum_max, the
+ * largest row sum of the Laplacian weights of the WHOLE mesh (max |wVtx| of MeshStats), which the caller passes so
+ * that every rank runs the same sequence.  State ghosts must be current on entry and are on return. */
+int fem_plan_run_imex_fused_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, double rel_tol, double wsum_max,
+                                    const fem_imex_comm *comm, void *stream);
 /* gathers this rank's send rows of ANY device vector of n_local pairs (fem_plan_pack_halo does it for the state) */
 int fem_plan_pack_vector(fem_plan *p, uint64_t dev_vector, uint64_t dst_dev, void *stream);
 /* device pointer of the current state buffer (interleaved (n - base_n,

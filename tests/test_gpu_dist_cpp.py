@@ -161,6 +161,34 @@ def test_sharded_semi_implicit_steps(sphere_off, tmp_path, ranks, transport):
     parity(raw[:V], raw[V:], n_ref, c_ref, 1e-10)
 
 
+@pytest.mark.parametrize("ranks,transport,fuse", [(1, "rccl", 4), (2, "inproc", 4), (3, "inproc", 3)])
+def test_sharded_semi_implicit_steps_on_fused_tiles(sphere_off, tmp_path, ranks, transport, fuse):
+    """fem_dist_run_imex_fused: the Chebyshev solver on the shards' fused tiles -- every rank iterates its owned AND ghost
+    rows, `fuse` iterations per launch, and fetches iterate and direction of its ghost rows after every launch; no
+    all-reduce, the coefficient sequence follows from the whole mesh's largest row sum, which every rank is given --
+    against the single-GPU run of the same solver (fem_plan_run_imex_fused, itself checked against scipy direct solves
+    in test_gpu_implicit.py): the same iterations on the same numbers, so they agree to rounding"""
+    iters, scale, tol = 3, 6.0, 1e-10
+    dump = str(tmp_path / "imexf.bin")
+    cmd = [FEM_RUN, sphere_off, "--ranks", str(ranks), "-n", str(NPARTS), "--fuse", str(fuse), "--iterations", str(iters), "--seed", "3",
+           "--transport", transport, "--imex-fused", str(tol), "--dt-scale", str(scale), "--f64", "--dump", dump]
+    run_fem(cmd)
+    raw = np.fromfile(dump)
+    V = len(raw) // 2
+    pts, tri, _ = fa.off_read(sphere_off)
+    part = fa.Mesh(pts, tri).partition(NPARTS)
+    om = part.ordered
+    om.init_stats(fa.PREC_F64)
+    dt = scale * 0.1 * om.stats()["maxEdgeLen"] ** 2
+    plan = fa.Plan(om, fa.PREC_F64, part=part, ksteps=fuse)
+    n0, c0 = fa.initial_condition(om.V, 3)
+    plan.set_state(n0, c0)
+    plan.run_imex_fused(2 + 2 * iters, dt, fa.default_model(), rel_tol=tol)
+    n_ref, c_ref = plan.get_state()
+    assert V == om.V and not np.array_equal(n_ref, n0)
+    parity(raw[:V], raw[V:], n_ref, c_ref, 1e-11)
+
+
 def test_failing_rank_does_not_hang_the_others(sphere_off, tmp_path):
     """a rank whose exchange fails (injected: FEM_DIST_TEST_FAIL_RANK) breaks the in-process barrier: the other ranks
     return an error at once instead of waiting for it, and the program exits non-zero with both messages"""
