@@ -553,6 +553,29 @@ def main():
                               "sustained": sustained_of(vr, args.sustained_steps) if args.sustained_steps > 0 else None}
             del vr
 
+    # ---- the same plan taking SEMI-IMPLICIT steps (diffusion implicit by Chebyshev iteration on the fused tiles,
+    # fem_plan_run_imex_fused; no counterpart in the reference): how far it advances the model per millisecond
+    # against the explicit steps just timed.  Not checked here (no oracle for it at this size): tests/test_gpu_implicit.py
+    # compares it with scipy direct solves at oracle sizes.
+    semi_implicit = None
+    if variants is not None and scanned is False and hasattr(runner.plan, "run_imex_fused"):
+        factor, tol_si, nsi = 30.0, 1e-4, 5
+        state_keep = runner.plan.get_state()
+        runner.plan.run_imex_fused(2, factor * runner.dt, runner.model, rel_tol=tol_si, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.plan.run_imex_fused(nsi, factor * runner.dt, runner.model, rel_tol=tol_si, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        si = (time.perf_counter() - t0) / nsi
+        ns_, _ = runner.plan.get_state()
+        runner.plan.set_state(*state_keep)
+        explicit_ms = (sustained["ms_per_step"] if sustained else wall * 1e3 / args.steps)
+        semi_implicit = {"dt_over_explicit_dt": factor, "tolerance": tol_si, "chebyshev_iterations": runner.plan.imex_fused_iterations(),
+                         "ms_per_step": si * 1e3, "explicit_ms_per_step_same_plan": explicit_ms,
+                         "simulated_time_per_ms_vs_these_explicit_steps": factor * explicit_ms / (si * 1e3),
+                         "state_finite": bool(np.isfinite(ns_).all()),
+                         "checked": "against scipy direct solves at oracle sizes (tests/test_gpu_implicit.py), not at this size"}
+
     verify_failed = False
     if rank == 0:
         ms_per_step = wall * 1e3 / args.steps
@@ -587,7 +610,7 @@ def main():
                        "host_threads_per_rank": int(os.environ.get("FEM_HOST_THREADS", "0")) or None,
                        "tiles": runner.plan.tile_info() if getattr(runner, "plan", None) is not None else None,
                        "halo_rings": getattr(runner, "krings", None), "mesh": mesh_report, "sustained": sustained,
-                       "variants": variants,
+                       "variants": variants, "semi_implicit": semi_implicit,
                        "parallelism": "1 rank" if world == 1 else "%d ranks (%s), partition ranges + halo exchange%s" % (
                            world, "RCCL" if args.dist_backend == "nccl" else "gloo rehearsal, halo staged through the host",
                            "" if getattr(runner, "fallback_reason", None) is None else
