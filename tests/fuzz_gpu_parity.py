@@ -14,7 +14,7 @@ from helpers import Case, rel_l2, smooth_ic, stable_dt   # noqa: E402
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 ol.set_threads(16)
-worst = {"f32": 0.0, "f64": 0.0, "fused_vs_sell": 0.0}
+worst = {"f32": 0.0, "f64": 0.0, "fused_vs_sell": 0.0, "mixed": 0.0, "imex_cheb_vs_cg": 0.0}
 for it in range(cases):
     regular = rng.random() < 0.6
     nu = int(rng.integers(6, 90))
@@ -53,7 +53,30 @@ for it in range(cases):
             assert e <= (1e-11 if name == "f64" else 1e-5), (name, e)
             assert np.isfinite(out[0][0]).all()
             res[name] = e
-        print("ok  ", tag, "f64 %.1e f32 %.1e packed=%d" % (res["f64"], res["f32"], fused.operator_format()), flush=True)
+        if cfg in (8, 2):
+            # the reference's precision mix on the same tiles, against the f64 oracle; and the two semi-implicit solvers
+            # (Chebyshev on the fused tiles, conjugate gradients on the sliced-ELL plan) against each other
+            ref = st.step(n0s, c0s, dt, steps, case.model.as_array())
+            mixed = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps, mixed=True)
+            mixed.set_state(n0s, c0s)
+            mixed.run(steps, dt, case.model)
+            mo = mixed.get_state()
+            res["mixed"] = max(rel_l2(mo[0], ref[0]), rel_l2(mo[1], ref[1]))
+            worst["mixed"] = max(worst["mixed"], res["mixed"])
+            assert res["mixed"] <= 1e-8, ("mixed", res["mixed"])
+            tiled = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=ksteps)
+            cg = fa.Plan(case.mesh, fa.PREC_F64, implicit=True)
+            for pl in (tiled, cg):
+                pl.set_state(n0s, c0s)
+            tiled.run_imex_fused(3, 5 * dt, case.model, rel_tol=1e-12)
+            cg.imex_tolerance(1e-12)
+            cg.run_imex(3, 5 * dt, case.model, 500)
+            (na, ca), (nb, cb) = tiled.get_state(), cg.get_state()
+            res["imex"] = max(rel_l2(na, nb), rel_l2(ca, cb))
+            worst["imex_cheb_vs_cg"] = max(worst["imex_cheb_vs_cg"], res["imex"])
+            assert res["imex"] <= 1e-9, ("imex", res["imex"])
+        print("ok  ", tag, "f64 %.1e f32 %.1e packed=%d" % (res["f64"], res["f32"], fused.operator_format()),
+              ("mixed %.1e imex %.1e" % (res["mixed"], res["imex"])) if "mixed" in res else "", flush=True)
     except Exception as ex:      # noqa: BLE001
         print("FAIL", tag, type(ex).__name__, ex, flush=True)
         if "FEM_ERR" not in str(ex) and "limit" not in str(ex).lower():
