@@ -332,6 +332,9 @@ int fem_dist_run_imex(fem_dist *d, int nsteps, double dt, const fem_model *model
 int fem_dist_run_imex_fused(fem_dist *d, int nsteps, double dt, const fem_model *model, double rel_tol, double wsum_max, void *stream) {
   if (!d) return fail(FEM_ERR_INVALID, "fem_dist_run_imex_fused: null");
   g_detail.clear();
+  // a launch takes up to ksteps iterations on the ghost rows as they stand: the shard needs at least that many rings
+  if (d->ksteps < 1 || d->krings < d->ksteps)
+    return fail(FEM_ERR_INVALID, "fem_dist_run_imex_fused: needs a fused-tile plan whose fused depth does not exceed the shard's ghost rings");
   fem_imex_comm comm = {d, imexExchange, imexAllreduce};       // the Chebyshev solver calls the exchange only
   const int rc = fem_plan_run_imex_fused_sharded(d->plan, nsteps, dt, model, rel_tol, wsum_max, &comm, stream);
   if (rc != FEM_OK && g_detail.empty()) g_detail = fem_error_detail();

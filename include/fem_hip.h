@@ -399,7 +399,8 @@ typedef struct {
 } fem_imex_comm;
 int fem_plan_run_imex_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, int cg_iterations, fem_uint n_own,
                               const fem_imex_comm *comm, void *stream);
-/* fem_plan_run_imex_fused on a shard's fused-tile plan (fem_plan_create_tiled with the shard; ksteps <= its ghost rings).
+/* fem_plan_run_imex_fused on a shard's fused-tile plan (fem_plan_create_tiled with the shard; the CALLER guarantees
+ * ksteps <= the shard's ghost rings -- fem_dist_run_imex_fused checks it -- or ghost rows go stale inside a launch).
  * Only comm->exchange is used: the right-hand side once, iterate and direction after every launch of ksteps
  * iterations, the new state at the end -- no all-reduce, because the Chebyshev coefficients come from wsum_max, the
  * largest row sum of the Laplacian weights of the WHOLE mesh (max |wVtx| of MeshStats), which the caller passes so

@@ -200,3 +200,12 @@ def test_failing_rank_does_not_hang_the_others(sphere_off, tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=env)
     assert res.returncode not in (0, 124) and time.time() - t0 < 25, (res.returncode, res.stderr[-2000:])
     assert "injected failure of rank 1" in res.stderr and "barrier broken" in res.stderr, res.stderr[-2000:]
+
+
+def test_fused_tile_solver_refuses_fewer_rings_than_iterations_per_launch(sphere_off):
+    """--imex-fused with --fuse 4 on shards of 2 ghost rings: a launch would iterate ghost rows that went stale two
+    iterations earlier; the host refuses instead of computing on them"""
+    cmd = [FEM_RUN, sphere_off, "--ranks", "2", "-n", str(NPARTS), "--fuse", "4", "--rings", "2", "--iterations", "2", "--transport", "inproc",
+           "--imex-fused", "1e-8", "--f64", "--watchdog", "60"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "ghost rings" in res.stderr, (res.returncode, res.stderr[-1500:])
