@@ -22,3 +22,6 @@ run python tools/bench_assembly.py 640 200 tile
 run python tools/bench_ref_step.py 640 250 100                                     # drop-in step() at 4M
 run python tools/bench_imex.py 640 20 30 30 1e-4                                   # semi-implicit stepping, kernel constants, dt = 30 x explicit
 run python tools/bench_imex.py 640 20 60 160 1e-4 host                             # the same with the reference's host constants, dt = 160 x explicit
+run python tools/bench_imex_fused.py 640 20 30 1e-4                                # semi-implicit stepping on the fused tiles (Chebyshev), kernel constants
+run python tools/bench_imex_fused.py 640 20 160 1e-4 host                          # the same with the reference's host constants
+run python bench.py --workload sphere16m --steps 1000 --precision mixed --no-cpu-baseline   # config 3 in the reference's own precision mix
