@@ -408,11 +408,12 @@ static int runImex(fem_plan *p, int nsteps, double dt, const fem_model *model, i
   return FEM_OK;
 }
 
-// Semi-implicit steps on a fused-tile plan (kernels_implicit.hpp, second half): right-hand side by one pass of the tile
-// kernel, then ceil(N / k) launches of k Chebyshev iterations each, N from the spectrum bounds and the tolerance.
+// Semi-implicit steps on a fused-tile plan (kernels_implicit.hpp, second half): one launch for the right-hand side and the
+// first k - 1 Chebyshev iterations (tile_rhs_cheb_kernel: the operator rows are in registers anyway), then launches of k
+// iterations each on the weights alone (tile_cheb_kernel); N iterations in all, from the spectrum bounds and the tolerance.
 // comm != null: the plan is a shard's.  Every launch runs ALL local tiles (the ghost rows are iterated locally, a ring less
 // valid per iteration), and the ghost rows of a vector are fetched from their owners through comm->exchange: the
-// right-hand side once, the iterate and the direction after every launch of k iterations, the new state at the end -- 2 L
+// right-hand side once, the iterate and the direction after every launch but the last, the new state at the end -- 2 L
 // exchanges per step for L launches, and no all-reduce: the spectrum bound `wsum` is the same number on every rank (the
 // caller passes the whole mesh's), so all ranks run the same coefficient sequence.
 template <typename T, int C>
@@ -452,7 +453,12 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
   }
   N = std::min(N, 100000);
   p->cheb_iters = N;
-  const int k = p->ksteps, launches = (N + k - 1) / k;
+  // The first launch computes the right-hand side and, from the same register rows, the first k - 1 iterations
+  // (tile_rhs_cheb_kernel); FEM_IMEX_FUSED_RHS=0 (A/B knob) or k = 1: the right-hand side in a launch of its own.
+  static const bool rhsKnob = !(getenv("FEM_IMEX_FUSED_RHS") && !strcmp(getenv("FEM_IMEX_FUSED_RHS"), "0"));
+  const int k = p->ksteps;
+  const bool fuseRhs = rhsKnob && k >= 2;
+  const int nit0 = std::min(fuseRhs ? k - 1 : k, N), launches = 1 + (N - nit0 + k - 1) / k;
   const ModelT<T> m = {(T)(model->nMax - p->base_n), (T)model->D, (T)model->r, (T)model->alpha, (T)model->S, (T)dt, (T)p->base_n,
                        (T)(1.0 / (1.0 + p->base_n))};
   auto rhsKern = [&]() {
@@ -463,26 +469,38 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
       return p->mixed ? (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 2> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 2>)
                       : (p->maxExtra ? tile_rhs_kernel<T, TPB, R, kTileW, MINW, 2, 0> : tile_rhs_kernel<T, TPB, R, kTileW, MINW, 1, 0>);
   }();
+  auto rhsChebKern = [&]() {
+    if constexpr (sizeof(T) == 4)
+      return p->packed ? (p->maxExtra ? tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 2, 1> : tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 1, 1>)
+                       : (p->maxExtra ? tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 2, 0> : tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 1, 0>);
+    else
+      return p->mixed ? (p->maxExtra ? tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 2, 2> : tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 1, 2>)
+                      : (p->maxExtra ? tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 2, 0> : tile_rhs_cheb_kernel<T, TPB, R, kTileW, MINW, 1, 0>);
+  }();
   auto chebKern = p->maxExtra ? tile_cheb_kernel<T, TPB, R, kTileW, MINW, true> : tile_cheb_kernel<T, TPB, R, kTileW, MINW, false>;
   const fem_uint maxExtraEven = (p->maxExtra + 1) & ~1u;         // keeps the LDS arrays behind the iterate buffers aligned
   const size_t ldsRhs = 2 * (size_t)p->maxLocal * sizeof(T2) + (size_t)p->maxExtra * (sizeof(T4) + 4) +
                         (size_t)TPB * R * 4 * (1 + (tileOffsetsInLds(R) ? kTileW / 2 : 0));
   const size_t ldsCheb = 2 * (size_t)p->maxLocal * sizeof(T2) + (p->maxExtra ? (size_t)maxExtraEven * (sizeof(T) + 4) + (size_t)TPB * R * 4 : 0);
   if (ldsRhs > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rhsKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRhs));
+  if (ldsRhs > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rhsChebKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsRhs));
   if (ldsCheb > 64 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)chebKern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsCheb));
   for (int s = 0; s < nsteps; s++) {
     const T2 *u = (const T2 *)p->state[p->cur];
     T2 *out = (T2 *)p->state[p->cur ^ 1];
-    hipLaunchKernelGGL(rhsKern, dim3(p->ntiles), dim3(TPB), ldsRhs, st, u, (T2 *)p->cb_b, p->tmeta.p, p->tghost.p, p->tidx2.p,
-                       (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra, m);
-    { const int rc = ghosts(p->cb_b); if (rc != FEM_OK) return rc; }
+    if (!fuseRhs) {
+      hipLaunchKernelGGL(rhsKern, dim3(p->ntiles), dim3(TPB), ldsRhs, st, u, (T2 *)p->cb_b, p->tmeta.p, p->tghost.p, p->tidx2.p,
+                         (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra, m);
+      const int rc = ghosts(p->cb_b);
+      if (rc != FEM_OK) return rc;
+    }
     // x_0 = b; the iterate alternates between two buffers so that the last launch writes the plan's next state
     double rho[2] = {delta[0] / theta[0], delta[1] / theta[1]};
     const T2 *xin = (const T2 *)p->cb_b;
     int it = 0;
     for (int l = 0; l < launches; l++) {
       T2 *xout = ((launches - 1 - l) & 1) ? (T2 *)p->cb_x : out;
-      const int nit = std::min(k, N - it);
+      const int nit = l == 0 ? nit0 : std::min(k, N - it);
       ChebArgs<T> a;
       a.dtDn = (T)(dt * model->D); a.dtDc = (T)dt; a.first = l == 0;
       for (int j = 0; j < 8; j++) { a.c1n[j] = a.c2n[j] = a.c1c[j] = a.c2c[j] = 0; }
@@ -498,9 +516,17 @@ static int runImexFused(fem_plan *p, int nsteps, double dt, const fem_model *mod
           (f == 0 ? a.c1n : a.c1c)[j] = (T)c1; (f == 0 ? a.c2n : a.c2c)[j] = (T)c2;
         }
       }
-      hipLaunchKernelGGL(chebKern, dim3(p->ntiles), dim3(TPB), ldsCheb, st, xin, xout, (const T2 *)p->cb_b, (const T2 *)p->cb_d[l & 1],
-                         (T2 *)p->cb_d[(l & 1) ^ 1], p->tmeta.p, p->tghost.p, p->tidx2.p, (const T *)p->cb_tw, p->txinfo.p, p->ntiles,
-                         p->maxLocal, maxExtraEven, nit, a);
+      if (l == 0 && fuseRhs) {
+        ChebTail<T> tail;
+        tail.xout = xout; tail.dout = (T2 *)p->cb_d[1]; tail.nit = nit; tail.a = a;
+        hipLaunchKernelGGL(rhsChebKern, dim3(p->ntiles), dim3(TPB), ldsRhs, st, u, (T2 *)p->cb_b, p->tmeta.p, p->tghost.p, p->tidx2.p,
+                           (const T4 *)p->tcoef, p->txinfo.p, p->ntiles, p->maxLocal, p->maxExtra, m, tail);
+        if (launches > 1) { const int rc = ghosts(p->cb_b); if (rc != FEM_OK) return rc; }
+      } else {
+        hipLaunchKernelGGL(chebKern, dim3(p->ntiles), dim3(TPB), ldsCheb, st, xin, xout, (const T2 *)p->cb_b, (const T2 *)p->cb_d[l & 1],
+                           (T2 *)p->cb_d[(l & 1) ^ 1], p->tmeta.p, p->tghost.p, p->tidx2.p, (const T *)p->cb_tw, p->txinfo.p, p->ntiles,
+                           p->maxLocal, maxExtraEven, nit, a);
+      }
       xin = xout;
       if (comm && l + 1 < launches) {
         int rc = ghosts(xout);

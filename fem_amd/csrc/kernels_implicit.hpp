@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void imex_clamp_kernel(typename Vec<T>::t2 *__
 // field (D_n = D, D_c = 1).  Per row the kernel keeps b and d in registers; ring rows reload the owner's d each launch.
 // The operator stream is the Laplacian weights alone (4 or 8 B per entry, extracted once: tile_weights_kernel).
 // ---------------------------------------------------------------------------------------------------------------
-template <typename T> struct ChebArgs { T c1n[8], c2n[8], c1c[8], c2c[8], dtDn, dtDc; int first; };
+// (ChebArgs: kernels_step.hpp, beside the tile body whose MODE 2 runs the first iterations behind the right-hand side)
 
 // weights of the register rows out of a plan's tile blocks: fmt 0 four scalars, 1 twelve-byte records (fp32), 2 mixed records (fp64)
 template <typename T>

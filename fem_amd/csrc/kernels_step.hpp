@@ -252,12 +252,19 @@ template <bool COH, typename T2> __device__ __forceinline__ void state_store(T2 
 
 // MODE 1 (tile_rhs_kernel, semi-implicit stepping on fused tiles): the step's update is the explicit right-hand side
 // b = u + dt (reaction + chemotaxis terms) without the diffusion terms and without the clamp (imex_rhs_update).
+// MODE 2 (tile_rhs_cheb_kernel): that right-hand side, then -- in the same launch, the operator rows still in registers --
+// the first tail->nit <= k - 1 Chebyshev iterations of the two diffusion solves from x_0 = b (kernels_implicit.hpp has
+// the iteration): the right-hand side used up one ring of the tile, every iteration uses up one more.  Writes b (dst),
+// the iterate and the direction of the owned rows.
+template <typename T> struct ChebArgs { T c1n[8], c2n[8], c1c[8], c2c[8], dtDn, dtDc; int first; };
+template <typename T> struct ChebTail { typename Vec<T>::t2 *xout, *dout; int nit; ChebArgs<T> a; };
+
 template <typename T, int TPB, int R, int W, int X, int PRO, int PK, int COH, int MODE = 0>
 __device__ __forceinline__ void tile_body(
     const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ dst,
     const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
     const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint tile,
-    uint maxLocal, uint maxExtra, int nsteps, const ModelT<T> &m) {
+    uint maxLocal, uint maxExtra, int nsteps, const ModelT<T> &m, const ChebTail<T> *tail = nullptr) {
   static_assert(PK != 1 || sizeof(T) == 4, "packed operator records: fp32 plans");
   static_assert(PK != 2 || sizeof(T) == 8, "mixed operator records: fp64 plans");
   typedef typename Vec<T>::t2 T2;
@@ -441,6 +448,7 @@ __device__ __forceinline__ void tile_body(
   }
   __syncthreads();
 
+  T2 bb[MODE == 2 ? R : 1];                              // MODE 2: the right-hand side of this thread's rows
   for (int s = 0; s < nsteps; s++) {
     const uint lim = mt[5 + k - 1 - s];
 #pragma unroll
@@ -500,13 +508,70 @@ __device__ __forceinline__ void tile_body(
             gcx += c.y * dc; gcy += c.z * dc; gcz += c.w * dc;
           }
         }
-        if constexpr (MODE == 1) nxt[r] = imex_rhs_update<T>(self, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+        if constexpr (MODE == 2) nxt[r] = bb[q] = imex_rhs_update<T>(self, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
+        else if constexpr (MODE == 1) nxt[r] = imex_rhs_update<T>(self, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
         else nxt[r] = reaction_update<T>(self, lapn, lapc, gnx, gny, gnz, gcx, gcy, gcz, m);
       }
       if constexpr (kTileRowFence) __builtin_amdgcn_sched_barrier(0);      // one row at a time: keeps the live set within 128 VGPRs
     }
     __syncthreads();
     T2 *tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if constexpr (MODE == 2) {
+    // cur = b = x_0 on the rows of all but the outermost ring.  Iteration s reads one ring more than it writes.
+    const ChebArgs<T> &a = tail->a;
+    T2 dd[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      dd[q].x = 0; dd[q].y = 0;
+      if (t + TPB * q < n0) dst[base + t + TPB * q] = bb[q];
+    }
+    for (int s = 0; s < tail->nit; s++) {
+      const uint lim = mt[5 + k - 2 - s];
+      const T c1n = a.c1n[s], c2n = a.c2n[s], c1c = a.c1c[s], c2c = a.c2c[s];
+#pragma unroll
+      for (int q = 0; q < R; q++) {
+        const uint r = t + TPB * q;
+        if (r < lim) {
+          const T2 self = cur[r];
+          if (IXL && q >= (X == 1 ? 1 : 0)) {
+#pragma unroll
+            for (int w = 0; w < W / 2; w++) ix[q][w] = xs_ix[w * (TPB * R) + r];
+          }
+#pragma unroll
+          for (int w = 0; w < W / 2; w++) asm volatile("" : "+v"(ix[q][w]));
+          T ln = 0, lc = 0;
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            const uint joff = (w & 1) ? (ix[q][w >> 1] >> 16) : (ix[q][w >> 1] & 0xffffu);
+            const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + joff);
+            T wt;
+            if constexpr (PK == 2) wt = mw[q][w]; else wt = cf[q][w].x;
+            ln += wt * (f.x - self.x); lc += wt * (f.y - self.y);
+          }
+          if (X && xcnt) {
+            const uint xi = xs_info[r];
+            for (uint e = xi & 0xffffu, ee = e + (xi >> 16); e < ee; e++) {
+              const T2 f = *reinterpret_cast<const T2 *>(reinterpret_cast<const unsigned char *>(cur) + xs_off[e]);
+              const T wt = xs_coef[e].x;
+              ln += wt * (f.x - self.x); lc += wt * (f.y - self.y);
+            }
+          }
+          const T rn = bb[q].x - (self.x - a.dtDn * ln), rc = bb[q].y - (self.y - a.dtDc * lc);
+          dd[q].x = c1n * dd[q].x + c2n * rn; dd[q].y = c1c * dd[q].y + c2c * rc;
+          T2 o;
+          o.x = self.x + dd[q].x; o.y = self.y + dd[q].y;
+          nxt[r] = o;
+        }
+      }
+      __syncthreads();
+      T2 *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    for (uint i = t; i < n0; i += TPB) tail->xout[base + i] = cur[i];
+#pragma unroll
+    for (int q = 0; q < R; q++)
+      if (t + TPB * q < n0) tail->dout[base + t + TPB * q] = dd[q];
+    return;
   }
   for (uint i = t; i < n0; i += TPB) state_store<(COH == 1 || COH == 3)>(&dst[base + i], cur[i]);
 }
@@ -532,6 +597,18 @@ __global__ __launch_bounds__(TPB, MINW) void tile_rhs_kernel(
   const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
   const uint tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);
   tile_body<T, TPB, R, W, X, 1, PK, 0, 1>(src, dst, meta, ghost, idx2, coef, xinfo, tile, maxLocal, maxExtra, 1, m);
+}
+
+// the same right-hand side and, with the operator rows still in registers, the first nit <= k - 1 Chebyshev iterations
+template <typename T, int TPB, int R, int W, int MINW, int X, int PK>
+__global__ __launch_bounds__(TPB, MINW) void tile_rhs_cheb_kernel(
+    const typename Vec<T>::t2 *__restrict__ src, typename Vec<T>::t2 *__restrict__ bout,
+    const uint *__restrict__ meta, const uint *__restrict__ ghost, const uint *__restrict__ idx2,
+    const typename Vec<T>::t4 *__restrict__ coef, const uint *__restrict__ xinfo, uint ntiles,
+    uint maxLocal, uint maxExtra, ModelT<T> m, ChebTail<T> tail) {
+  const uint b = blockIdx.x, q8 = ntiles >> 3, r8 = ntiles & 7u, x = b & 7u;
+  const uint tile = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (b >> 3);
+  tile_body<T, TPB, R, W, X, 1, PK, 0, 2>(src, bout, meta, ghost, idx2, coef, xinfo, tile, maxLocal, maxExtra, 1, m, &tail);
 }
 
 // ---------------------------------------------------------------------------

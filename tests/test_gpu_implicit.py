@@ -109,13 +109,15 @@ def test_imex_requires_flag_and_layout():
 
 @pytest.mark.parametrize("make,nparts,factor,ksteps", [(lambda n: sphere_case(16, n), 6, 1.0, 4), (lambda n: sphere_case(16, n), 6, 8.0, 4),
                                                        (lambda n: sphere_case(24, n), 8, 30.0, 7), (lambda n: strip_case(n), 3, 4.0, 3),
-                                                       (lambda n: scan_case(16, n), 5, 6.0, 4)])
+                                                       (lambda n: scan_case(16, n), 5, 6.0, 4),
+                                                       (lambda n: sphere_case(16, n), 6, 2.0, 1), (lambda n: scan_case(16, n), 5, 2.0, 2)])
 def test_imex_on_fused_tiles_matches_scipy(make, nparts, factor, ksteps):
     """fem_plan_run_imex_fused: the same semi-implicit step on a fused-tile plan, the diffusion solves by Chebyshev
     iteration (ksteps iterations per launch, no dot products) -- against the scipy direct solves, in fp64 (tolerance
     1e-12: as close as the CG path), in the reference's precision mix and in fp32 with 12-byte records (1e-6); the
     iteration count is the a-priori one and grows with the time step; the irregular mesh exercises the rows of more than
-    6 entries (extras staged in LDS)"""
+    6 entries (extras staged in LDS).  From ksteps = 2 on the first launch of a solve is tile_rhs_cheb_kernel (right-hand
+    side + ksteps - 1 iterations from the same register rows); ksteps = 1 keeps the right-hand side in a launch of its own"""
     case = make(nparts)
     case.mesh.init_stats(fa.PREC_F64)
     st = case.ostats(ol.F64)
@@ -142,6 +144,22 @@ def test_imex_on_fused_tiles_matches_scipy(make, nparts, factor, ksteps):
     n32, c32 = plan32.get_state()
     e32 = parity(n32, c32, n_ref, c_ref, 1e-5, tol_dev=1e-3)
     print("fused imex: %d iterations; f64 %s; f32 %s" % (its, e, e32))
+
+
+def test_imex_on_fused_tiles_solve_within_the_first_launch():
+    """a time step so short that the whole solve fits behind the right-hand side in ONE launch (iterations <= ksteps - 1):
+    the launch writes the plan's next state itself"""
+    case = sphere_case(16, 6)
+    case.mesh.init_stats(fa.PREC_F64)
+    st = case.ostats(ol.F64)
+    dt = 0.02 * stable_dt(st, case.model, safety=1.0)
+    n0, c0 = smooth_ic(case.pts)
+    n_ref, c_ref = scipy_imex(st, case.topo, n0, c0, dt, 3, case.model.as_array())
+    plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=8)
+    plan.set_state(n0, c0)
+    plan.run_imex_fused(3, dt, case.model, rel_tol=1e-9)
+    assert 1 <= plan.imex_fused_iterations() <= 7, plan.imex_fused_iterations()
+    parity(*plan.get_state(), n_ref, c_ref, 1e-9)
 
 
 def test_imex_on_fused_tiles_refuses_what_it_does_not_cover():
