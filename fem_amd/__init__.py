@@ -248,6 +248,13 @@ class Mesh:
         _check(lib.fem_compute_vertex_gradients_cpu(self.h, _ptr(fg, f64p), _ptr(out, f64p)))
         return out
 
+    def spectrum_bound(self):
+        """upper bound on the largest eigenvalue of -L (assembled Laplacian of the stats): the smaller of Gershgorin's and the
+        per-triangle bound (fem_mesh_spectrum_bound); the Chebyshev solver of run_imex_fused takes its interval from it"""
+        b = C.c_double()
+        _check(lib.fem_mesh_spectrum_bound(self.h, C.byref(b)))
+        return b.value
+
     def wide_rows_first(self, width=6):
         """-> (Mesh, new_index): vertices renumbered stably by their number of entries beyond `width`, most first
         (fem_mesh_wide_rows_first); (self, None) when no row is wider"""

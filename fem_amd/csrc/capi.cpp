@@ -324,6 +324,14 @@ int fem_mesh_stats(const fem_mesh *m, const double **meshAngle, const double **m
   });
 }
 
+int fem_mesh_spectrum_bound(const fem_mesh *m, double *bound) {
+  return fem::guarded("fem_mesh_spectrum_bound", [&]() -> int {
+  if (!m || !bound || m->stats.precision < 0) return fail(FEM_ERR_INVALID, "fem_mesh_spectrum_bound: stats not initialised");
+  *bound = fem::laplacianSpectrumBound(m->mesh, m->stats);
+  return FEM_OK;
+  });
+}
+
 int fem_compute_laplacian_cpu(const fem_mesh *m, const double *fn, double *lap) {
   return fem::guarded("fem_compute_laplacian_cpu", [&]() -> int {
   if (!m || m->stats.precision < 0 || !fn || !lap) return fail(FEM_ERR_INVALID, "fem_compute_laplacian_cpu: bad argument");

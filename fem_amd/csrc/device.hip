@@ -827,10 +827,16 @@ static int planCreate(const fem_mesh *ordered, const fem::Shard *shard, int prec
   (void)hipGetDevice(&p->device);
   p->base_n = model->nMax; p->base_c = model->nMax / (1 + model->nMax);
   p->precision = precision; p->V = op.V;
+  // half a rigorous bound on the spectrum of -L (the Chebyshev solver's interval): Gershgorin on the rows as packed,
+  // or the per-triangle bound of the mesh's stats where that is smaller (a whole-mesh plan; shards are given theirs)
   for (fem::uint r = 0; r < op.V; r++) {
     double ws = 0;
-    for (fem::uint q = op.rowptr[r]; q < op.rowptr[r + 1]; q++) ws += op.coef[4 * (size_t)q];
+    for (fem::uint q = op.rowptr[r]; q < op.rowptr[r + 1]; q++) ws += std::fabs(op.coef[4 * (size_t)q]);
     if (ws > p->wsum_max) p->wsum_max = ws;
+  }
+  if (!shard) {
+    const double sb = fem::laplacianSpectrumBound(ordered->mesh, ordered->stats);
+    if (sb > 0 && 0.5 * sb < p->wsum_max) p->wsum_max = 0.5 * sb;
   }
   if (const char *e = getenv("FEM_TILE_PROLOGUE")) p->prologue = std::min(3, std::max(0, atoi(e)));
   if (const char *e = getenv("FEM_SELL_NT")) p->sell_nt = atoi(e) != 0;

@@ -99,6 +99,9 @@ template <typename Fn> void parallelFor(size_t n, size_t grain, Fn fn) {
   for (auto &e : err) if (e) std::rethrow_exception(e);
 }
 
+// rigorous upper bound on the largest eigenvalue of -L (assembled Laplacian rows of the stats); mesh_stats.cpp
+double laplacianSpectrumBound(const SimpleTriMesh &m, const MeshStats &s);
+
 // records status + message for fem_last_error()/fem_error_detail(); returns status
 int fail(int status, const char *what);
 

@@ -275,11 +275,10 @@ double shardedRun(int n, const Options &o, const fem_model &model, const Run &r)
   const int R = o.ranks;
   if (n < R) { std::fprintf(stderr, "--ranks %d needs at least that many partitions (have %d)\n", R, n); return -1; }
   const int krings = o.krings > 0 ? o.krings : (o.imex > 0 ? 1 : (o.imexFused > 0 ? std::max(1, o.fuse) : std::max(2, 2 * o.fuse)));
-  double wsumMax = 0;                // spectrum bound of the Chebyshev solver: the whole mesh's largest |wVtx| (the same on every rank)
+  double wsumMax = 0;                // the Chebyshev solver's interval: half the whole mesh's spectrum bound (the same on every rank)
   if (o.imexFused > 0) {
-    const double *wVtx = nullptr;
-    if (!ok(fem_mesh_stats(r.ordered, nullptr, nullptr, nullptr, nullptr, nullptr, &wVtx, nullptr, nullptr, nullptr), "stats") || !wVtx) return -1;
-    for (int i = 0; i < r.V; i++) wsumMax = std::max(wsumMax, std::fabs(wVtx[i]));
+    if (!ok(fem_mesh_spectrum_bound(r.ordered, &wsumMax), "spectrum bound") || !(wsumMax > 0)) return -1;
+    wsumMax *= 0.5;
   }
   const int ndev = std::max(1, fem_dist_device_count());
   if (!o.inproc && R > ndev) {     // RCCL refuses (or hangs on) two ranks of one communicator on the same GPU

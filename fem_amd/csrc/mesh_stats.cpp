@@ -122,6 +122,35 @@ template <typename G> void assemble(const SimpleTriMesh &m, MeshStats &s, const 
 
 }  // namespace
 
+// Upper bound on the spectrum of -L, L = M^-1 K the assembled Laplacian rows (wHej, wVtx): what the Chebyshev solver of
+// the semi-implicit step needs (device.hip:runImexFused).  The smaller of two rigorous bounds:
+//  * Gershgorin on the rows, with absolute values (obtuse triangles give negative weights): |wVtx| + sum |wHej|;
+//  * element by element: K is the sum of the triangles' stiffness matrices K_t (edge weights cot / 2: the Dirichlet
+//    energy of a linear function, positive semi-definite whatever the angles) and M of their lumped masses M_t = A_t / 3
+//    per corner, so x'Kx = sum_t x_t'K_t x_t <= sum_t lambda_t x_t'M_t x_t <= (max_t lambda_t) x'Mx with
+//    lambda_t = (3 / A_t) (w1 + w2 + w3 + sqrt(w1^2 + w2^2 + w3^2 - w1 w2 - w2 w3 - w3 w1)), the largest eigenvalue of a
+//    three-vertex graph Laplacian with weights w_i = cot_i / 2.  On a regular mesh this is the exact largest eigenvalue
+//    (6 / h^2) where Gershgorin gives 8 / h^2.
+// Faces with zero area (a shard's stats hold only the faces its rows need) are skipped; 0 when there are no stats.
+double laplacianSpectrumBound(const SimpleTriMesh &m, const MeshStats &s) {
+  const size_t V = m.n_vertices(), F = m.n_faces(), H = m.he_from.size();
+  if (s.precision < 0 || s.wVtx.size() != V || s.wHej.size() != H || s.meshCot.size() < 3 * F || s.meshArea.size() != F) return 0;
+  std::vector<double> rowAbs(V, 0.0);
+  for (size_t h = 0; h < H; h++) rowAbs[m.he_from[h]] += std::fabs(s.wHej[h]);
+  double gersh = 0;
+  for (size_t v = 0; v < V; v++) gersh = std::max(gersh, std::fabs(s.wVtx[v]) + rowAbs[v]);
+  double elem = 0;
+  for (size_t f = 0; f < F; f++) {
+    const double A = s.meshArea[f];
+    if (!(A > 0)) continue;
+    const double w1 = 0.5 * s.meshCot[3 * f], w2 = 0.5 * s.meshCot[3 * f + 1], w3 = 0.5 * s.meshCot[3 * f + 2];
+    const double lam = (3.0 / A) * (w1 + w2 + w3 + std::sqrt(std::max(0.0, w1 * w1 + w2 * w2 + w3 * w3 - w1 * w2 - w2 * w3 - w3 * w1)));
+    if (!std::isfinite(lam)) return gersh;
+    elem = std::max(elem, lam);
+  }
+  return elem > 0 ? std::min(gersh, elem) : gersh;
+}
+
 void initMeshStats(SimpleTriMesh &ipMesh, MeshStats &mStats, int precision) {
   if (ipMesh.H == 0) ipMesh.update_topology();
   mStats.precision = precision;

@@ -60,7 +60,7 @@ int fem_dist_run(fem_dist *d, int nsteps, double dt, const fem_model *model, voi
 int fem_dist_run_imex(fem_dist *d, int nsteps, double dt, const fem_model *model, int cg_iterations, void *stream);
 /* The same steps on a shard's FUSED-TILE plan with the Chebyshev solver (fem_plan_run_imex_fused_sharded): halo
  * exchanges only -- right-hand side, then iterate and direction once per launch of ksteps iterations -- and no
- * all-reduce anywhere; wsum_max = the whole mesh's largest |wVtx| (the same number on every rank). */
+ * all-reduce anywhere; wsum_max = half the whole mesh's fem_mesh_spectrum_bound (the same number on every rank). */
 int fem_dist_run_imex_fused(fem_dist *d, int nsteps, double dt, const fem_model *model, double rel_tol, double wsum_max, void *stream);
 /* makes `stream` wait for an exchange still in flight (call before reading the state back) */
 int fem_dist_wait(fem_dist *d, void *stream);

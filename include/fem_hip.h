@@ -205,6 +205,14 @@ int fem_mesh_stats(const fem_mesh *m, const double **meshAngle, const double **m
                    const double **wVtx, double *maxEdgeLen, const double **gradVec12,
                    const double **gradVec13);
 
+/* Upper bound on the largest eigenvalue of -L, L the assembled Laplacian (wHej, wVtx of the stats): the smaller of
+ * Gershgorin's row bound and the largest per-triangle eigenvalue lambda_max(M_t^-1 K_t) (exact on regular meshes, where
+ * Gershgorin is a third too large).  Both are rigorous, obtuse triangles included.  What the Chebyshev solver of the
+ * semi-implicit step takes its coefficients from (fem_plan_run_imex_fused uses it by itself; sharded runs pass HALF of the
+ * whole mesh's bound as `wsum_max`).  No counterpart in the reference (mesh_function.cpp:490-586 sketches implicit
+ * stepping, with no solver). */
+int fem_mesh_spectrum_bound(const fem_mesh *m, double *bound);
+
 /* CPU operators kept by name (mesh_function.h:6-110), on the mesh handle. */
 int fem_compute_laplacian_cpu(const fem_mesh *m, const double *fn, double *lap);
 int fem_compute_face_gradients_cpu(const fem_mesh *m, const double *fn, double *faceGrad /*3F*/);
@@ -402,9 +410,9 @@ int fem_plan_run_imex_sharded(fem_plan *p, int nsteps, double dt, const fem_mode
 /* fem_plan_run_imex_fused on a shard's fused-tile plan (fem_plan_create_tiled with the shard; the CALLER guarantees
  * ksteps <= the shard's ghost rings -- fem_dist_run_imex_fused checks it -- or ghost rows go stale inside a launch).
  * Only comm->exchange is used: the right-hand side once, iterate and direction after every launch of ksteps
- * iterations, the new state at the end -- no all-reduce, because the Chebyshev coefficients come from wsum_max, the
- * largest row sum of the Laplacian weights of the WHOLE mesh (max |wVtx| of MeshStats), which the caller passes so
- * that every rank runs the same sequence.  State ghosts must be current on entry and are on return. */
+ * iterations, the new state at the end -- no all-reduce, because the Chebyshev coefficients come from wsum_max, HALF an
+ * upper bound on the spectrum of -L of the WHOLE mesh (fem_mesh_spectrum_bound / 2; max |wVtx| of MeshStats is the
+ * Gershgorin value for meshes without obtuse angles), which the caller passes so that every rank runs the same sequence.  State ghosts must be current on entry and are on return. */
 int fem_plan_run_imex_fused_sharded(fem_plan *p, int nsteps, double dt, const fem_model *model, double rel_tol, double wsum_max,
                                     const fem_imex_comm *comm, void *stream);
 /* gathers this rank's send rows of ANY device vector of n_local pairs (fem_plan_pack_halo does it for the state) */
