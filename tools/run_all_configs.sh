@@ -25,3 +25,5 @@ run python tools/bench_imex.py 640 20 60 160 1e-4 host                          
 run python tools/bench_imex_fused.py 640 20 30 1e-4                                # semi-implicit stepping on the fused tiles (Chebyshev), kernel constants
 run python tools/bench_imex_fused.py 640 20 160 1e-4 host                          # the same with the reference's host constants
 run python bench.py --workload sphere16m --steps 1000 --precision mixed --no-cpu-baseline   # config 3 in the reference's own precision mix
+run python tools/bench_imex_fused.py 900 10 30 1e-4 kernel scan                   # semi-implicit stepping on the irregular 8.1M mesh of config 4, dt = 30 x its explicit step
+run python tools/bench_imex_fused.py 900 10 200 1e-4 kernel scan                  # ... dt = 200 x
