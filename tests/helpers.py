@@ -85,6 +85,22 @@ def scan_case(nu=24, nparts=8, mesh_seed=3, **kw):
     return Case(pts, tri, nparts, **kw)
 
 
+def stretched_sheet(n=9, seed=5):
+    """an open sheet of n x n jittered points, three times as long as wide: most triangles are obtuse, so many
+    cotangent weights are NEGATIVE (what twice the largest row sum is no spectrum bound for)"""
+    rng = np.random.default_rng(seed)
+    pts = np.array([[x + 0.35 * rng.standard_normal(), 3.0 * y + 0.35 * rng.standard_normal(), 0.0] for y in range(n) for x in range(n)])
+    tri = np.array([t for y in range(n - 1) for x in range(n - 1)
+                    for t in ((n * y + x, n * y + x + 1, n * y + x + n + 1), (n * y + x, n * y + x + n + 1, n * y + x + n))])
+    return pts, tri
+
+
+def stretched_case(n=24, nparts=4, scale=0.02, **kw):
+    """... scaled down so that a time step of a few diffusion limits stays inside the reaction term's explicit limit"""
+    pts, tri = stretched_sheet(n)
+    return Case(pts * scale, tri, nparts, **kw)
+
+
 def stable_dt(stats, model, safety=0.2):
     """explicit-Euler step well inside the diffusion limit of an irregular mesh (the reference's
     dt = 0.1 maxEdgeLen^2 assumes near-uniform triangles)"""

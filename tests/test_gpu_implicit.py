@@ -162,6 +162,26 @@ def test_imex_on_fused_tiles_solve_within_the_first_launch():
     parity(*plan.get_state(), n_ref, c_ref, 1e-9)
 
 
+def test_imex_on_fused_tiles_with_negative_weights():
+    """a stretched, jittered sheet: most triangles obtuse, a third of the cotangent weights negative, the spectrum of -L
+    reaching beyond twice the largest row sum -- the Chebyshev interval must still contain it (per-triangle bound /
+    Gershgorin with absolute values, fem_mesh_spectrum_bound), or the iteration diverges instead of matching scipy"""
+    from helpers import stretched_case
+    case = stretched_case(24, 4)
+    case.mesh.init_stats(fa.PREC_F64)
+    st = case.ostats(ol.F64)
+    w = np.asarray(st.wHej)
+    assert (w < 0).mean() > 0.05, (w < 0).mean()
+    dt = 20.0 * stable_dt(st, case.model, safety=1.0)
+    n0, c0 = smooth_ic(case.pts)
+    n_ref, c_ref = scipy_imex(st, case.topo, n0, c0, dt, 4, case.model.as_array())
+    plan = fa.Plan(case.mesh, fa.PREC_F64, part=case.part, ksteps=4)
+    plan.set_state(n0, c0)
+    plan.run_imex_fused(4, dt, case.model, rel_tol=1e-12)
+    parity(*plan.get_state(), n_ref, c_ref, 1e-9)
+    assert case.mesh.spectrum_bound() > 2.0 * float(np.abs(np.asarray(st.wVtx)).max())
+
+
 def test_imex_on_fused_tiles_refuses_what_it_does_not_cover():
     sp_ = sphere_case(6, 2)
     sp_.mesh.init_stats(fa.PREC_F64)

@@ -549,9 +549,8 @@ def test_spectrum_bound_against_dense_eigenvalues():
     usual class-I factor) 1.19 x the true value where Gershgorin is 1.59 x"""
     import fem_amd as fa
     from helpers import sphere_case, strip_case, scan_case, pathological_scan
-    rng = np.random.default_rng(5)
-    sq_pts = np.array([[x + 0.35 * rng.standard_normal(), 3.0 * y + 0.35 * rng.standard_normal(), 0.0] for y in range(9) for x in range(9)])
-    sq_tri = np.array([t for y in range(8) for x in range(8) for t in ((9 * y + x, 9 * y + x + 1, 9 * y + x + 10), (9 * y + x, 9 * y + x + 10, 9 * y + x + 9))])
+    from helpers import stretched_sheet
+    sq_pts, sq_tri = stretched_sheet(9)
     ps_pts, ps_tri = pathological_scan(10)
     meshes = [("sphere", fa.Mesh(*fa.make_icosphere(8, 0.1))), ("strip", strip_case(3).mesh), ("scan", scan_case(10, 4).mesh),
               ("stretched", fa.Mesh(sq_pts, sq_tri)), ("pathological", fa.Mesh(ps_pts, ps_tri))]
