@@ -418,10 +418,16 @@ def main():
         # ... except whole meshes of 192..2400 such tiles: fem_plan_run runs those in persistent launches (device.hip:
         # persistRule), which do not need many small tiles to fill the workgroup slots
         small = False
+    # tiny meshes (config 1: 10k vertices) cannot fill the chip with tiles of several hundred rows: they take the deepest
+    # fusion and ~ 160 small tiles instead (same-box sweep on sphere10k: 13.3 G with 13 tiles at k = 6, 22.1 G with 160 tiles
+    # of 64 rows at k = 8; 40-row tiles 15.8 G)
+    tiny = not scanned and V_total // world < 150000
     if args.fuse < 0:
-        args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if scanned else ("6" if small else "7")))
+        args.fuse = int(os.environ.get("FEM_FUSE_STEPS", "5" if scanned else ("8" if tiny else ("6" if small else "7"))))
     tile_n0 = int(os.environ.get("FEM_TILE_N0", ({4: "950", 5: "820" if scanned else "880", 6: "760", 7: "650"} if small else
                                                  {5: "1200", 6: "1050", 7: "975", 8: "900"}).get(args.fuse, "820")))
+    if tiny and "FEM_TILE_N0" not in os.environ:
+        tile_n0 = min(tile_n0, max(64, V_total // world // 160))
     nparts = max(world, V_total // (tile_n0 if args.fuse > 0 else wl["verts_per_part"]))
     deform = wl.get("deform", False)
     if deform:
